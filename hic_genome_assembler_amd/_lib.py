@@ -1,0 +1,230 @@
+"""ctypes binding of libhicmi.so (include/hicmi.h) - the only way the Python host reaches the GPU.
+
+There is deliberately no fallback: if the library has not been built, or no HIP device is
+visible, the calls raise.  Build with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C hic_genome_assembler_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhicmi.so")
+_lib = None
+
+c_i64 = ctypes.c_int64
+c_dbl = ctypes.c_double
+_vp = ctypes.c_void_p
+
+# name: (restype, argtypes) - one row per declaration in include/hicmi.h
+SIGNATURES = {
+    "hicmi_abi_version": (ctypes.c_int, []),
+    "hicmi_last_error": (ctypes.c_char_p, []),
+    "hicmi_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "hicmi_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    "hicmi_destroy": (ctypes.c_int, [_vp]),
+    "hicmi_stream": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    "hicmi_synchronize": (ctypes.c_int, [_vp]),
+    "hicmi_set_contacts_host": (ctypes.c_int, [_vp, _vp, c_i64]),
+    "hicmi_set_contacts_device": (ctypes.c_int, [_vp, _vp, c_i64, c_i64]),
+    "hicmi_row_sums": (ctypes.c_int, [_vp, _vp, _vp]),
+    "hicmi_compact": (ctypes.c_int, [_vp, _vp, c_i64]),
+    "hicmi_upgma": (ctypes.c_int, [_vp, _vp, _vp]),
+    "hicmi_rank_matrix": (ctypes.c_int, [_vp, _vp]),
+    "hicmi_get_rank_rows": (ctypes.c_int, [_vp, c_i64, c_i64, ctypes.c_int, _vp]),
+    "hicmi_get_similarity_row": (ctypes.c_int, [_vp, c_i64, _vp]),
+    "hicmi_cut_scan": (ctypes.c_int, [_vp, c_i64, c_i64, c_dbl, _vp, _vp]),
+    "hicmi_filter_scan": (ctypes.c_int, [_vp, c_i64, c_i64, c_i64, c_i64, c_dbl, _vp, _vp]),
+    "hicmi_hypergeom_sf": (c_dbl, [c_i64, c_i64, c_i64, c_i64]),
+    "hicmi_label_linkage": (ctypes.c_int, [_vp, c_i64, _vp]),
+    "hicmi_leaf_order": (ctypes.c_int, [_vp, c_i64, _vp]),
+    "hicmi_get_raw_merges": (ctypes.c_int, [_vp, _vp]),
+    "hicmi_p2_select": (ctypes.c_int, [_vp, _vp, c_i64]),
+    "hicmi_p2_total": (ctypes.c_int, [_vp, ctypes.POINTER(c_dbl)]),
+    "hicmi_p2_score": (ctypes.c_int, [_vp, _vp, c_i64, c_i64, c_dbl, _vp]),
+    "hicmi_timing_reset": (ctypes.c_int, [_vp]),
+    "hicmi_timing_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "hicmi_timing_get": (ctypes.c_int, [_vp, ctypes.c_char_p, c_i64, _vp, _vp, _vp, c_i64, ctypes.POINTER(c_i64)]),
+}
+
+
+class HicmiError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libhicmi.so and attach signatures.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HicmiError("libhicmi.so is not built (%s): run `make -C %s` - this package has no CPU fallback"
+                         % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hicmi_abi_version() != 1:
+        raise HicmiError("libhicmi ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise HicmiError("libhicmi error %d: %s" % (rc, load().hicmi_last_error().decode("utf-8", "replace")))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def hypergeom_sf(x, M, n, N) -> float:
+    """hyper_geom(x, M, n, N) of scaffoldToChromosomes.py:352-368, evaluated by libhicmi's host code."""
+    return float(load().hicmi_hypergeom_sf(int(x), int(M), int(n), int(N)))
+
+
+class Context:
+    """One GPU context (hicmi_ctx): owns the device-resident contact matrix and all stage buffers."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        h = _vp()
+        _check(self._lib.hicmi_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self.n = 0
+        self._keepalive = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hicmi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- contacts
+    def set_contacts(self, mat: np.ndarray):
+        mat = np.ascontiguousarray(mat, dtype=np.float64)
+        if mat.ndim != 2 or mat.shape[0] != mat.shape[1]:
+            raise ValueError("contact matrix must be square")
+        _check(self._lib.hicmi_set_contacts_host(self._h, _ptr(mat), mat.shape[0]))
+        self.n = mat.shape[0]
+
+    def set_contacts_device(self, data_ptr: int, n: int, ld: int | None = None, keepalive=None):
+        _check(self._lib.hicmi_set_contacts_device(self._h, _vp(data_ptr), n, n if ld is None else ld))
+        self.n = n
+        self._keepalive = keepalive
+
+    def row_sums(self):
+        np_sum = np.empty(self.n, np.float64)
+        seq = np.empty(self.n, np.float64)
+        _check(self._lib.hicmi_row_sums(self._h, _ptr(np_sum), _ptr(seq)))
+        return np_sum, seq
+
+    def compact(self, keep):
+        keep = np.ascontiguousarray(keep, dtype=np.int32)
+        _check(self._lib.hicmi_compact(self._h, _ptr(keep), len(keep)))
+        self.n = len(keep)
+
+    # ---- Part 1
+    def upgma(self, want_linkage: bool = True):
+        z = np.empty((max(self.n - 1, 0), 4), np.float64) if want_linkage else None
+        leaves = np.empty(self.n, np.int32)
+        _check(self._lib.hicmi_upgma(self._h, _ptr(z), _ptr(leaves)))
+        return leaves, z
+
+    def raw_merges(self):
+        z = np.empty((max(self.n - 1, 0), 4), np.float64)
+        _check(self._lib.hicmi_get_raw_merges(self._h, _ptr(z)))
+        return z
+
+    def rank_matrix(self, order):
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        if len(order) != self.n:
+            raise ValueError("order must have n entries")
+        _check(self._lib.hicmi_rank_matrix(self._h, _ptr(order)))
+
+    def rank_rows(self, row0=0, nrows=None, inverse=False):
+        nrows = self.n - row0 if nrows is None else nrows
+        out = np.empty((nrows, self.n), np.uint16)
+        _check(self._lib.hicmi_get_rank_rows(self._h, row0, nrows, 1 if inverse else 0, _ptr(out)))
+        return out
+
+    def similarity_row(self, row):
+        out = np.empty(self.n, np.float64)
+        _check(self._lib.hicmi_get_similarity_row(self._h, row, _ptr(out)))
+        return out
+
+    def cut_scan(self, start, M, psig, want_x=False):
+        cnt = self.n - start
+        sig = np.empty(cnt, np.uint8)
+        x = np.empty(cnt, np.int32) if want_x else None
+        _check(self._lib.hicmi_cut_scan(self._h, start, M, psig, _ptr(x), _ptr(sig)))
+        return (sig, x) if want_x else sig
+
+    def filter_scan(self, start, c, n_rows, M, psig, want_x=False):
+        sig = np.empty(n_rows, np.uint8)
+        x = np.empty(n_rows, np.int32) if want_x else None
+        _check(self._lib.hicmi_filter_scan(self._h, start, c, n_rows, M, psig, _ptr(x), _ptr(sig)))
+        return (sig, x) if want_x else sig
+
+    # ---- Part 2
+    def p2_select(self, sel):
+        sel = np.ascontiguousarray(sel, dtype=np.int32)
+        _check(self._lib.hicmi_p2_select(self._h, _ptr(sel), len(sel)))
+
+    def p2_total(self) -> float:
+        t = c_dbl()
+        _check(self._lib.hicmi_p2_total(self._h, ctypes.byref(t)))
+        return t.value
+
+    def p2_score(self, perms, total: float):
+        perms = np.ascontiguousarray(perms, dtype=np.int32)
+        if perms.ndim != 2:
+            raise ValueError("perms must be (n_cand, n_used)")
+        out = np.empty(perms.shape[0], np.float64)
+        if perms.shape[0]:
+            _check(self._lib.hicmi_p2_score(self._h, _ptr(perms), perms.shape[0], perms.shape[1], float(total), _ptr(out)))
+        return out
+
+    # ---- misc
+    def synchronize(self):
+        _check(self._lib.hicmi_synchronize(self._h))
+
+    def stream(self) -> int:
+        s = _vp()
+        _check(self._lib.hicmi_stream(self._h, ctypes.byref(s)))
+        return s.value or 0
+
+    def timing_enable(self, on=True):
+        _check(self._lib.hicmi_timing_enable(self._h, 1 if on else 0))
+
+    def timing_reset(self):
+        _check(self._lib.hicmi_timing_reset(self._h))
+
+    def timing(self):
+        names = ctypes.create_string_buffer(1024)
+        ms = np.zeros(32, np.float64)
+        launches = np.zeros(32, np.int64)
+        nbytes = np.zeros(32, np.float64)
+        cnt = c_i64()
+        _check(self._lib.hicmi_timing_get(self._h, names, 1024, _ptr(ms), _ptr(launches), _ptr(nbytes), 32,
+                                          ctypes.byref(cnt)))
+        out = {}
+        for k, nm in enumerate(names.value.decode().split(";")[:cnt.value]):
+            out[nm] = dict(ms=float(ms[k]), launches=int(launches[k]), bytes=float(nbytes[k]))
+        return out

@@ -1,0 +1,655 @@
+// api.hip - the C ABI of libhicmi.so (include/hicmi.h): context, device buffers, stage drivers,
+// and the small host-side pieces of SciPy's linkage post-processing.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/hicmi.h"
+#include "hicmi_internal.h"
+#include "hyper.h"
+
+using namespace hicmi;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) return fail(HICMI_EHIP, "%s: %s", #expr, hipGetErrorString(_e));     \
+    } while (0)
+
+enum Family { F_ROW_SUMS, F_BUILD_W, F_NNCHAIN, F_SORT, F_RANK_INVERT, F_CUT_COUNT, F_HYPER_FLAGS, F_P2_SELECT,
+              F_P2_TOTAL, F_P2_SCORE, F_COUNT };
+static const char* kFamilyNames[F_COUNT] = {"row_sums", "build_w", "nnchain", "sort_rows", "rank_invert",
+                                            "cut_count", "hyper_flags", "p2_select", "p2_total", "p2_score"};
+
+struct TimedRegion { int fam; hipEvent_t a, b; };
+
+struct hicmi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // contacts
+    int64_t n = 0, ldc = 0;
+    double* dC = nullptr;
+    bool own_c = false;
+    double *d_np = nullptr, *d_seq = nullptr;
+    bool have_sums = false;
+    // upgma
+    double* dW = nullptr; int64_t ldw = 0; int64_t w_rows = 0;
+    int *d_size = nullptr, *d_chain = nullptr, *d_status = nullptr;
+    double* d_zraw = nullptr;
+    std::vector<double> zraw;
+    // rank matrix
+    int32_t* d_order = nullptr;
+    uint16_t *dR = nullptr, *dRank = nullptr; int64_t ldr = 0; int64_t r_rows = 0;
+    void* d_sort_scratch = nullptr; size_t sort_scratch_cap = 0;
+    bool have_rank = false;
+    // cut scan
+    int32_t* d_x = nullptr; uint8_t* d_sig = nullptr; int64_t x_cap = 0;
+    int64_t cached_start = -1;
+    double* d_tmp = nullptr; int64_t tmp_cap = 0;
+    // part 2
+    double* dM2 = nullptr; int64_t n2 = 0, ld2 = 0, m2_cap = 0;
+    int32_t* d_sel = nullptr; int64_t sel_cap = 0;
+    double* d_H = nullptr; int64_t h_cap = 0;
+    int32_t* d_perms = nullptr; int64_t perms_cap = 0;
+    double* d_scores = nullptr; int64_t scores_cap = 0;
+    double* d_partial = nullptr; int64_t partial_cap = 0;
+    // timing
+    bool timing = false;
+    std::vector<TimedRegion> regions;
+    std::vector<hipEvent_t> pool;
+    double ms[F_COUNT] = {0}; int64_t launches[F_COUNT] = {0}; double bytes[F_COUNT] = {0};
+};
+
+namespace {
+struct Timed {
+    hicmi_ctx* c; int fam; hipEvent_t a = nullptr, b = nullptr;
+    Timed(hicmi_ctx* ctx, int f, double algo_bytes) : c(ctx), fam(f)
+    {
+        c->launches[f]++; c->bytes[f] += algo_bytes;
+        if (!c->timing) return;
+        a = grab(); b = grab();
+        hipEventRecord(a, c->stream);
+    }
+    ~Timed()
+    {
+        if (!c->timing) return;
+        hipEventRecord(b, c->stream);
+        c->regions.push_back({fam, a, b});
+    }
+    hipEvent_t grab()
+    {
+        if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+        hipEvent_t e; hipEventCreate(&e); return e;
+    }
+};
+
+int resolve_timing(hicmi_ctx* c)
+{
+    if (c->regions.empty()) return HICMI_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto& r : c->regions) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) c->ms[r.fam] += ms;
+        c->pool.push_back(r.a); c->pool.push_back(r.b);
+    }
+    c->regions.clear();
+    return HICMI_OK;
+}
+
+template <typename T>
+int ensure(T*& p, int64_t& cap, int64_t need)
+{
+    if (need <= cap && p) return HICMI_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    if (need <= 0) need = 1;
+    hipError_t e = hipMalloc((void**)&p, (size_t)need * sizeof(T));
+    if (e != hipSuccess) { p = nullptr; return fail(HICMI_ENOMEM, "hipMalloc(%lld bytes): %s", (long long)(need * (int64_t)sizeof(T)), hipGetErrorString(e)); }
+    cap = need;
+    return HICMI_OK;
+}
+
+void free_dev(void* p) { if (p) (void)hipFree(p); }
+
+void drop_matrix_state(hicmi_ctx* c)
+{
+    if (c->own_c) free_dev(c->dC);
+    c->dC = nullptr; c->own_c = false; c->n = 0; c->ldc = 0;
+    free_dev(c->d_np); free_dev(c->d_seq); c->d_np = c->d_seq = nullptr; c->have_sums = false;
+    c->have_rank = false; c->cached_start = -1; c->n2 = 0;
+}
+
+int alloc_sums(hicmi_ctx* c)
+{
+    HIPCHK(hipMalloc((void**)&c->d_np, sizeof(double) * (size_t)std::max<int64_t>(c->n, 1)));
+    HIPCHK(hipMalloc((void**)&c->d_seq, sizeof(double) * (size_t)std::max<int64_t>(c->n, 1)));
+    return HICMI_OK;
+}
+
+int compute_sums(hicmi_ctx* c)
+{
+    if (c->have_sums) return HICMI_OK;
+    if (!c->dC) return fail(HICMI_EINVAL, "no contact matrix set");
+    {
+        Timed t(c, F_ROW_SUMS, 2.0 * 8.0 * (double)c->n * (double)c->n);
+        launch_row_sums(c->dC, c->ldc, (int)c->n, c->d_np, c->d_seq, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    c->have_sums = true;
+    return HICMI_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int hicmi_abi_version(void) { return HICMI_ABI_VERSION; }
+const char* hicmi_last_error(void) { return g_err.c_str(); }
+
+int hicmi_device_count(int* count)
+{
+    if (!count) return fail(HICMI_EINVAL, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(HICMI_EHIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return HICMI_OK;
+}
+
+int hicmi_create(int device, hicmi_ctx** out)
+{
+    if (!out) return fail(HICMI_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(HICMI_EHIP, "no HIP device available (%s): libhicmi has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= n) return fail(HICMI_EINVAL, "device %d out of range (0..%d)", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    hicmi_ctx* c = new hicmi_ctx();
+    c->device = device;
+    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) { delete c; return fail(HICMI_EHIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
+    *out = c;
+    return HICMI_OK;
+}
+
+int hicmi_destroy(hicmi_ctx* c)
+{
+    if (!c) return HICMI_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    drop_matrix_state(c);
+    free_dev(c->dW); free_dev(c->d_size); free_dev(c->d_chain); free_dev(c->d_status); free_dev(c->d_zraw);
+    free_dev(c->d_order); free_dev(c->dR); free_dev(c->dRank); free_dev(c->d_sort_scratch);
+    free_dev(c->d_x); free_dev(c->d_sig); free_dev(c->d_tmp);
+    free_dev(c->dM2); free_dev(c->d_sel); free_dev(c->d_H); free_dev(c->d_perms); free_dev(c->d_scores);
+    free_dev(c->d_partial);
+    for (auto& r : c->regions) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return HICMI_OK;
+}
+
+int hicmi_stream(hicmi_ctx* c, void** stream_out)
+{
+    if (!c || !stream_out) return fail(HICMI_EINVAL, "NULL argument");
+    *stream_out = (void*)c->stream;
+    return HICMI_OK;
+}
+
+int hicmi_synchronize(hicmi_ctx* c)
+{
+    if (!c) return fail(HICMI_EINVAL, "NULL context");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HICMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int hicmi_set_contacts_host(hicmi_ctx* c, const double* contacts, int64_t n)
+{
+    if (!c || !contacts || n < 1) return fail(HICMI_EINVAL, "bad arguments");
+    if (n > 65536) return fail(HICMI_EUNSUPPORTED, "n = %lld > 65536 bins: rank matrix is uint16 in this version", (long long)n);
+    HIPCHK(hipSetDevice(c->device));
+    drop_matrix_state(c);
+    c->n = n; c->ldc = n;
+    HIPCHK(hipMalloc((void**)&c->dC, sizeof(double) * (size_t)n * (size_t)n));
+    c->own_c = true;
+    HIPCHK(hipMemcpyAsync(c->dC, contacts, sizeof(double) * (size_t)n * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return alloc_sums(c);
+}
+
+int hicmi_set_contacts_device(hicmi_ctx* c, const double* d_contacts, int64_t n, int64_t ld)
+{
+    if (!c || !d_contacts || n < 1 || ld < n) return fail(HICMI_EINVAL, "bad arguments");
+    if (n > 65536) return fail(HICMI_EUNSUPPORTED, "n = %lld > 65536 bins: rank matrix is uint16 in this version", (long long)n);
+    HIPCHK(hipSetDevice(c->device));
+    drop_matrix_state(c);
+    c->n = n; c->ldc = ld; c->dC = const_cast<double*>(d_contacts); c->own_c = false;
+    return alloc_sums(c);
+}
+
+int hicmi_row_sums(hicmi_ctx* c, double* np_sum, double* seq_sum)
+{
+    if (!c) return fail(HICMI_EINVAL, "NULL context");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = compute_sums(c);
+    if (rc) return rc;
+    if (np_sum) HIPCHK(hipMemcpyAsync(np_sum, c->d_np, sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    if (seq_sum) HIPCHK(hipMemcpyAsync(seq_sum, c->d_seq, sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HICMI_OK;
+}
+
+int hicmi_compact(hicmi_ctx* c, const int32_t* keep, int64_t n_keep)
+{
+    if (!c || !keep || n_keep < 1) return fail(HICMI_EINVAL, "bad arguments");
+    if (!c->dC || !c->own_c) return fail(HICMI_EINVAL, "hicmi_compact needs a matrix set with hicmi_set_contacts_host");
+    if (n_keep > c->n) return fail(HICMI_EINVAL, "n_keep > n");
+    for (int64_t i = 0; i < n_keep; i++)
+        if (keep[i] < 0 || keep[i] >= c->n || (i && keep[i] <= keep[i - 1])) return fail(HICMI_EINVAL, "keep must be ascending indices in [0, n)");
+    HIPCHK(hipSetDevice(c->device));
+    int32_t* d_keep = nullptr; double* d_new = nullptr;
+    HIPCHK(hipMalloc((void**)&d_keep, sizeof(int32_t) * (size_t)n_keep));
+    HIPCHK(hipMalloc((void**)&d_new, sizeof(double) * (size_t)n_keep * (size_t)n_keep));
+    HIPCHK(hipMemcpyAsync(d_keep, keep, sizeof(int32_t) * (size_t)n_keep, hipMemcpyHostToDevice, c->stream));
+    launch_compact(c->dC, c->ldc, d_keep, (int)n_keep, d_new, n_keep, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    free_dev(d_keep);
+    drop_matrix_state(c);
+    c->dC = d_new; c->own_c = true; c->n = n_keep; c->ldc = n_keep;
+    int rc = alloc_sums(c);
+    if (rc) return rc;
+    return compute_sums(c);
+}
+
+// ---------------------------------------------------------------------------------------------------
+int hicmi_label_linkage(const double* zraw, int64_t n, double* Z)
+{
+    if (!zraw || !Z || n < 1) return fail(HICMI_EINVAL, "bad arguments");
+    const int64_t m = n - 1;
+    std::vector<int64_t> idx((size_t)m);
+    std::iota(idx.begin(), idx.end(), (int64_t)0);
+    // numpy argsort(kind='mergesort') on the heights: stable
+    std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return zraw[4 * a + 2] < zraw[4 * b + 2]; });
+    std::vector<int64_t> parent((size_t)(2 * n - 1)), sz((size_t)(2 * n - 1), 0);
+    for (int64_t i = 0; i < 2 * n - 1; i++) { parent[i] = i; if (i < n) sz[i] = 1; }
+    auto find = [&](int64_t x) {
+        int64_t p = x;
+        while (parent[x] != x) x = parent[x];
+        while (parent[p] != x) { int64_t nx = parent[p]; parent[p] = x; p = nx; }
+        return x;
+    };
+    int64_t next = n;
+    for (int64_t r = 0; r < m; r++) {
+        const double* s = zraw + 4 * idx[r];
+        int64_t a = find((int64_t)s[0]), b = find((int64_t)s[1]);
+        Z[4 * r + 0] = (double)std::min(a, b);
+        Z[4 * r + 1] = (double)std::max(a, b);
+        Z[4 * r + 2] = s[2];
+        parent[a] = next; parent[b] = next;
+        sz[next] = sz[a] + sz[b];
+        Z[4 * r + 3] = (double)sz[next];
+        next++;
+    }
+    return HICMI_OK;
+}
+
+int hicmi_leaf_order(const double* Z, int64_t n, int32_t* leaves)
+{
+    if (!Z || !leaves || n < 1) return fail(HICMI_EINVAL, "bad arguments");
+    if (n == 1) { leaves[0] = 0; return HICMI_OK; }
+    std::vector<int64_t> stack;
+    stack.reserve(64);
+    stack.push_back(2 * n - 2);
+    int64_t out = 0;
+    while (!stack.empty()) {
+        int64_t node = stack.back(); stack.pop_back();
+        if (node < n) { if (out >= n) return fail(HICMI_ESTATE, "malformed linkage"); leaves[out++] = (int32_t)node; continue; }
+        const double* row = Z + 4 * (node - n);
+        int64_t aa = (int64_t)row[0], ab = (int64_t)row[1];
+        int64_t na = aa < n ? 1 : (int64_t)Z[4 * (aa - n) + 3];
+        int64_t nb = ab < n ? 1 : (int64_t)Z[4 * (ab - n) + 3];
+        // count_sort='ascending': smaller child first; on equal counts keep (Z[i,0], Z[i,1]) order
+        if (na > nb) { stack.push_back(aa); stack.push_back(ab); }
+        else         { stack.push_back(ab); stack.push_back(aa); }
+    }
+    return out == n ? HICMI_OK : fail(HICMI_ESTATE, "malformed linkage (%lld leaves of %lld)", (long long)out, (long long)n);
+}
+
+int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
+{
+    if (!c || !leaves_out) return fail(HICMI_EINVAL, "bad arguments");
+    if (!c->dC) return fail(HICMI_EINVAL, "no contact matrix set");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = compute_sums(c);
+    if (rc) return rc;
+    const int64_t n = c->n;
+    if (n == 1) { leaves_out[0] = 0; c->zraw.clear(); return HICMI_OK; }
+    const int64_t ldw = (n + 15) & ~(int64_t)15;
+    if (c->w_rows < n || c->ldw != ldw || !c->dW) {
+        free_dev(c->dW); c->dW = nullptr;
+        HIPCHK(hipMalloc((void**)&c->dW, sizeof(double) * (size_t)n * (size_t)ldw));
+        c->ldw = ldw; c->w_rows = n;
+        free_dev(c->d_size); free_dev(c->d_chain); free_dev(c->d_zraw); free_dev(c->d_status);
+        c->d_size = c->d_chain = c->d_status = nullptr; c->d_zraw = nullptr;
+        HIPCHK(hipMalloc((void**)&c->d_size, sizeof(int) * (size_t)n));
+        HIPCHK(hipMalloc((void**)&c->d_chain, sizeof(int) * (size_t)(n + 2)));
+        HIPCHK(hipMalloc((void**)&c->d_zraw, sizeof(double) * 4 * (size_t)n));
+        HIPCHK(hipMalloc((void**)&c->d_status, sizeof(int)));
+    }
+    {
+        Timed t(c, F_BUILD_W, 8.0 * (0.5 * (double)n * (double)n + (double)n * (double)n));
+        launch_build_w(c->dC, c->ldc, c->d_np, (int)n, c->dW, ldw, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    {
+        // nominal algorithmic traffic of SciPy's nn_chain: <=3(n-1) row scans + per merge two row reads,
+        // one row write and one column write of 8-byte elements
+        Timed t(c, F_NNCHAIN, 8.0 * 7.0 * (double)n * (double)(n - 1));
+        launch_nnchain(c->dW, ldw, (int)n, c->d_size, c->d_chain, c->d_zraw, c->d_status, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    int status = 0;
+    c->zraw.assign((size_t)(4 * (n - 1)), 0.0);
+    HIPCHK(hipMemcpyAsync(&status, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->zraw.data(), c->d_zraw, sizeof(double) * 4 * (size_t)(n - 1), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (status != 0) return fail(HICMI_ESTATE, "nn-chain kernel stopped on its guard (NaN distances or an internal error)");
+    std::vector<double> Z((size_t)(4 * (n - 1)));
+    rc = hicmi_label_linkage(c->zraw.data(), n, Z.data());
+    if (rc) return rc;
+    rc = hicmi_leaf_order(Z.data(), n, leaves_out);
+    if (rc) return rc;
+    if (Z_out) memcpy(Z_out, Z.data(), sizeof(double) * Z.size());
+    return HICMI_OK;
+}
+
+int hicmi_get_raw_merges(hicmi_ctx* c, double* out)
+{
+    if (!c || !out) return fail(HICMI_EINVAL, "bad arguments");
+    if (c->zraw.empty()) return fail(HICMI_EINVAL, "hicmi_upgma has not run");
+    memcpy(out, c->zraw.data(), sizeof(double) * c->zraw.size());
+    return HICMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
+{
+    if (!c || !order) return fail(HICMI_EINVAL, "bad arguments");
+    if (!c->dC) return fail(HICMI_EINVAL, "no contact matrix set");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t n = c->n;
+    std::vector<uint8_t> seen((size_t)n, 0);
+    for (int64_t i = 0; i < n; i++) {
+        if (order[i] < 0 || order[i] >= n || seen[(size_t)order[i]]) return fail(HICMI_EINVAL, "order is not a permutation of 0..n-1");
+        seen[(size_t)order[i]] = 1;
+    }
+    int rc = compute_sums(c);
+    if (rc) return rc;
+    const int64_t ldr = (n + 63) & ~(int64_t)63;
+    if (c->r_rows < n || c->ldr != ldr || !c->dR) {
+        free_dev(c->dR); free_dev(c->dRank); free_dev(c->d_order); c->dR = c->dRank = nullptr; c->d_order = nullptr;
+        HIPCHK(hipMalloc((void**)&c->dR, sizeof(uint16_t) * (size_t)n * (size_t)ldr));
+        HIPCHK(hipMalloc((void**)&c->dRank, sizeof(uint16_t) * (size_t)n * (size_t)ldr));
+        HIPCHK(hipMalloc((void**)&c->d_order, sizeof(int32_t) * (size_t)n));
+        c->ldr = ldr; c->r_rows = n;
+    }
+    size_t need = sort_scratch_bytes((int)n);
+    if (need > c->sort_scratch_cap) {
+        free_dev(c->d_sort_scratch); c->d_sort_scratch = nullptr; c->sort_scratch_cap = 0;
+        HIPCHK(hipMalloc(&c->d_sort_scratch, need));
+        c->sort_scratch_cap = need;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_order, order, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    {
+        Timed t(c, F_SORT, (8.0 + 2.0) * (double)n * (double)n);
+        launch_sort_rows(c->dC, c->ldc, c->d_order, c->d_np, c->d_seq, (int)n, c->d_sort_scratch, c->dR, ldr, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    {
+        Timed t(c, F_RANK_INVERT, (2.0 + 2.0) * (double)n * (double)n);
+        launch_rank_invert(c->dR, c->dRank, ldr, (int)n, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_rank = true;
+    c->cached_start = -1;
+    return HICMI_OK;
+}
+
+int hicmi_get_rank_rows(hicmi_ctx* c, int64_t row0, int64_t nrows, int inverse, uint16_t* out)
+{
+    if (!c || !out || row0 < 0 || nrows < 0) return fail(HICMI_EINVAL, "bad arguments");
+    if (!c->have_rank) return fail(HICMI_EINVAL, "hicmi_rank_matrix has not run");
+    if (row0 + nrows > c->n) return fail(HICMI_EINVAL, "rows out of range");
+    HIPCHK(hipSetDevice(c->device));
+    const uint16_t* src = (inverse ? c->dRank : c->dR) + row0 * c->ldr;
+    HIPCHK(hipMemcpy2DAsync(out, sizeof(uint16_t) * (size_t)c->n, src, sizeof(uint16_t) * (size_t)c->ldr,
+                            sizeof(uint16_t) * (size_t)c->n, (size_t)nrows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HICMI_OK;
+}
+
+int hicmi_get_similarity_row(hicmi_ctx* c, int64_t row, double* out)
+{
+    if (!c || !out) return fail(HICMI_EINVAL, "bad arguments");
+    if (!c->have_rank) return fail(HICMI_EINVAL, "hicmi_rank_matrix has not run");
+    if (row < 0 || row >= c->n) return fail(HICMI_EINVAL, "row out of range");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure(c->d_tmp, c->tmp_cap, c->n);
+    if (rc) return rc;
+    launch_similarity_row(c->dC, c->ldc, c->d_order, c->d_np, c->d_seq, (int)c->n, (int)row, c->d_tmp, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, c->d_tmp, sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HICMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+static int ensure_scan_buffers(hicmi_ctx* c)
+{
+    if (c->x_cap >= c->n && c->d_x && c->d_sig) return HICMI_OK;
+    free_dev(c->d_x); free_dev(c->d_sig); c->d_x = nullptr; c->d_sig = nullptr; c->x_cap = 0;
+    HIPCHK(hipMalloc((void**)&c->d_x, sizeof(int32_t) * (size_t)c->n));
+    HIPCHK(hipMalloc((void**)&c->d_sig, (size_t)c->n));
+    c->x_cap = c->n;
+    return HICMI_OK;
+}
+
+int hicmi_cut_scan(hicmi_ctx* c, int64_t start, int64_t M, double psig, int32_t* x_out, uint8_t* sig_out)
+{
+    if (!c) return fail(HICMI_EINVAL, "NULL context");
+    if (!c->have_rank) return fail(HICMI_EINVAL, "hicmi_rank_matrix has not run");
+    const int64_t n = c->n;
+    if (start < 0 || start >= n) return fail(HICMI_EINVAL, "start out of range");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_scan_buffers(c);
+    if (rc) return rc;
+    const int64_t cnt = n - start;              // entries: rows start .. n-1
+    if (c->cached_start != start) {
+        HIPCHK(hipMemsetAsync(c->d_x, 0, sizeof(int32_t), c->stream));
+        const double m = (double)(cnt - 1);
+        Timed t(c, F_CUT_COUNT, 2.0 * (m * (m + 3.0) / 2.0));      // sum_{L=1..m} (L+1) uint16 entries
+        launch_cut_count(c->dRank, c->ldr, (int)start + 1, (int)(cnt - 1), (int)start, 0, 0, c->d_x + 1, c->stream);
+        HIPCHK(hipGetLastError());
+        c->cached_start = start;
+    }
+    {
+        Timed t(c, F_HYPER_FLAGS, 5.0 * (double)cnt);
+        launch_hyper_flags(c->d_x, (int)cnt, 0, 0, M, psig, c->d_sig, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    if (x_out) HIPCHK(hipMemcpyAsync(x_out, c->d_x, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
+    if (sig_out) HIPCHK(hipMemcpyAsync(sig_out, c->d_sig, (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HICMI_OK;
+}
+
+int hicmi_filter_scan(hicmi_ctx* c, int64_t start, int64_t cut, int64_t n_rows, int64_t M, double psig,
+                      int32_t* x_out, uint8_t* sig_out)
+{
+    if (!c) return fail(HICMI_EINVAL, "NULL context");
+    if (!c->have_rank) return fail(HICMI_EINVAL, "hicmi_rank_matrix has not run");
+    const int64_t n = c->n;
+    if (start < 0 || start >= n || cut < start || cut >= n || n_rows < 0 || start + n_rows > n)
+        return fail(HICMI_EINVAL, "filter scan arguments out of range");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_scan_buffers(c);
+    if (rc) return rc;
+    c->cached_start = -1;                       // d_x is reused
+    {
+        Timed t(c, F_CUT_COUNT, 2.0 * (double)n_rows * (double)(cut - start + 1));
+        launch_cut_count(c->dRank, c->ldr, (int)start, (int)n_rows, (int)start, 1, (int)cut, c->d_x, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    {
+        Timed t(c, F_HYPER_FLAGS, 5.0 * (double)n_rows);
+        launch_hyper_flags(c->d_x, (int)n_rows, 1, (int)(cut - start), M, psig, c->d_sig, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    if (x_out) HIPCHK(hipMemcpyAsync(x_out, c->d_x, sizeof(int32_t) * (size_t)n_rows, hipMemcpyDeviceToHost, c->stream));
+    if (sig_out) HIPCHK(hipMemcpyAsync(sig_out, c->d_sig, (size_t)n_rows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HICMI_OK;
+}
+
+double hicmi_hypergeom_sf(int64_t x, int64_t M, int64_t n, int64_t N) { return hypergeom_sf_ge(x, M, n, N); }
+
+// ---------------------------------------------------------------------------------------------------
+int hicmi_p2_select(hicmi_ctx* c, const int32_t* sel, int64_t n)
+{
+    if (!c || !sel || n < 1) return fail(HICMI_EINVAL, "bad arguments");
+    if (!c->dC) return fail(HICMI_EINVAL, "no contact matrix set");
+    for (int64_t i = 0; i < n; i++)
+        if (sel[i] < 0 || sel[i] >= c->n) return fail(HICMI_EINVAL, "selection index out of range");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t ld2 = (n + 15) & ~(int64_t)15;
+    int rc = ensure(c->dM2, c->m2_cap, n * ld2);
+    if (rc) return rc;
+    rc = ensure(c->d_sel, c->sel_cap, n);
+    if (rc) return rc;
+    // H[k] = 1 + 1/2 + ... + 1/k, left to right in fp64
+    if (c->h_cap < n + 1) {
+        std::vector<double> H((size_t)(n + 1));
+        H[0] = 0.0;
+        for (int64_t k = 1; k <= n; k++) H[(size_t)k] = H[(size_t)k - 1] + 1.0 / (double)k;
+        rc = ensure(c->d_H, c->h_cap, n + 1);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->d_H, H.data(), sizeof(double) * (size_t)(n + 1), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    HIPCHK(hipMemcpyAsync(c->d_sel, sel, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    {
+        Timed t(c, F_P2_SELECT, 16.0 * (double)n * (double)n);
+        launch_p2_select(c->dC, c->ldc, c->d_sel, (int)n, c->dM2, ld2, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->n2 = n; c->ld2 = ld2;
+    return HICMI_OK;
+}
+
+int hicmi_p2_total(hicmi_ctx* c, double* total_out)
+{
+    if (!c || !total_out) return fail(HICMI_EINVAL, "bad arguments");
+    if (c->n2 < 1) return fail(HICMI_EINVAL, "hicmi_p2_select has not run");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure(c->d_partial, c->partial_cap, c->n2 + 1);
+    if (rc) return rc;
+    {
+        Timed t(c, F_P2_TOTAL, 4.0 * (double)c->n2 * (double)c->n2);
+        launch_p2_total(c->dM2, c->ld2, (int)c->n2, c->d_partial, c->d_partial + c->n2, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(total_out, c->d_partial + c->n2, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HICMI_OK;
+}
+
+int hicmi_p2_score(hicmi_ctx* c, const int32_t* perms, int64_t n_cand, int64_t n_used, double total, double* scores_out)
+{
+    if (!c || !perms || !scores_out || n_cand < 0 || n_used < 1) return fail(HICMI_EINVAL, "bad arguments");
+    if (c->n2 < 1) return fail(HICMI_EINVAL, "hicmi_p2_select has not run");
+    if (n_used > c->n2) return fail(HICMI_EINVAL, "n_used exceeds the selection");
+    if (n_cand == 0) return HICMI_OK;
+    if (n_used * (int64_t)sizeof(int32_t) > 160 * 1024) return fail(HICMI_EUNSUPPORTED, "candidate longer than 40960 bins");
+    for (int64_t i = 0; i < n_cand * n_used; i++)
+        if (perms[i] < 0 || perms[i] >= c->n2) return fail(HICMI_EINVAL, "candidate index out of range");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure(c->d_perms, c->perms_cap, n_cand * n_used);
+    if (rc) return rc;
+    rc = ensure(c->d_scores, c->scores_cap, n_cand);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->d_perms, perms, sizeof(int32_t) * (size_t)(n_cand * n_used), hipMemcpyHostToDevice, c->stream));
+    {
+        Timed t(c, F_P2_SCORE, 8.0 * (double)n_cand * 0.5 * (double)n_used * (double)(n_used - 1));
+        launch_p2_score(c->dM2, c->ld2, c->d_perms, (int)n_cand, (int)n_used, c->d_H, 0.0, total, c->d_scores, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(scores_out, c->d_scores, sizeof(double) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HICMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int hicmi_timing_reset(hicmi_ctx* c)
+{
+    if (!c) return fail(HICMI_EINVAL, "NULL context");
+    int rc = resolve_timing(c);
+    if (rc) return rc;
+    for (int f = 0; f < F_COUNT; f++) { c->ms[f] = 0; c->launches[f] = 0; c->bytes[f] = 0; }
+    return HICMI_OK;
+}
+
+int hicmi_timing_enable(hicmi_ctx* c, int on)
+{
+    if (!c) return fail(HICMI_EINVAL, "NULL context");
+    int rc = resolve_timing(c);
+    if (rc) return rc;
+    c->timing = on != 0;
+    return HICMI_OK;
+}
+
+int hicmi_timing_get(hicmi_ctx* c, char* names_out, int64_t names_cap, double* ms_out, int64_t* launches_out,
+                     double* bytes_out, int64_t cap, int64_t* count_out)
+{
+    if (!c || !names_out || !ms_out || !launches_out || !bytes_out || !count_out) return fail(HICMI_EINVAL, "NULL argument");
+    if (cap < F_COUNT) return fail(HICMI_EINVAL, "need room for %d families", (int)F_COUNT);
+    int rc = resolve_timing(c);
+    if (rc) return rc;
+    std::string names;
+    for (int f = 0; f < F_COUNT; f++) {
+        if (f) names += ";";
+        names += kFamilyNames[f];
+        ms_out[f] = c->ms[f]; launches_out[f] = c->launches[f]; bytes_out[f] = c->bytes[f];
+    }
+    if ((int64_t)names.size() + 1 > names_cap) return fail(HICMI_EINVAL, "names buffer too small");
+    memcpy(names_out, names.c_str(), names.size() + 1);
+    *count_out = F_COUNT;
+    return HICMI_OK;
+}
+
+}  // extern "C"

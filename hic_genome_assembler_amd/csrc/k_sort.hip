@@ -1,0 +1,204 @@
+// k_sort.hip - per-row descending rank order of the reordered similarity matrix
+// (scaffoldToChromosomes.py:1131-1132: convertMatrix(similarity) then numpy.argsort(axis=1)[:, ::-1]).
+//
+// The similarity matrix is never materialised: a workgroup computes the keys of its row straight
+// from the contact matrix through the leaf order,
+//     d = (1. - c / rowsum_np) + 1.      (S2C:147, as stored by Part 1)
+//     s = rowsum_seq * (1. - (d - 1.))   (S2C:149)
+// maps fp64 -> order-preserving uint64, and sorts (key, column) pairs ascending with a bitonic
+// network: 8192-element tiles in LDS (80 KB), strides >= 8192 through a per-workgroup scratch
+// buffer that stays in L2/Infinity Cache.  Ascending (key, column) order reversed is "descending
+// similarity, ties by descending column" = numpy's stable argsort reversed - the tie rule this
+// build fixes (NumPy's default unstable sort leaves tie order undefined).
+#include "hicmi_internal.h"
+
+namespace hicmi {
+
+static constexpr int SORT_TILE = 8192;
+static constexpr int SORT_THREADS = 1024;
+
+int sort_padded_size(int n)
+{
+    int p = 2;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+int sort_workgroups(int n)
+{
+    int g = 512;                                   // 2 workgroups per CU (80 KB LDS each)
+    return n < g ? n : g;
+}
+
+size_t sort_scratch_bytes(int n)
+{
+    size_t P = (size_t)sort_padded_size(n);
+    return (size_t)sort_workgroups(n) * P * (sizeof(uint64_t) + sizeof(uint16_t));
+}
+
+__device__ __forceinline__ uint64_t key_of(double s)
+{
+    s = s + 0.0;                                   // -0.0 -> +0.0 (numpy compares them equal)
+    uint64_t u = (uint64_t)__double_as_longlong(s);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ double similarity(double c, double sig, double rs)
+{
+    double d = (1.0 - (c / sig)) + 1.0;
+    return rs * (1.0 - (d - 1.0));
+}
+
+__device__ __forceinline__ void cmpx(uint64_t* __restrict__ k, uint16_t* __restrict__ ix, int i, int l, bool asc)
+{
+    uint64_t ka = k[i], kb = k[l];
+    uint16_t ia = ix[i], ib = ix[l];
+    bool gt = ka > kb || (ka == kb && ia > ib);
+    if (gt == asc) { k[i] = kb; k[l] = ka; ix[i] = ib; ix[l] = ia; }
+}
+
+// all (k, j) stages with k in [k_lo, k_hi] and j < min(k, tile) on one LDS-resident tile
+__device__ __forceinline__ void lds_stages(uint64_t* lk, uint16_t* li, int tile, int base, int k_lo, int k_hi, int tid)
+{
+    for (int k = k_lo; k <= k_hi; k <<= 1) {
+        int j0 = (k >> 1) < tile ? (k >> 1) : (tile >> 1);
+        for (int j = j0; j >= 1; j >>= 1) {
+            for (int p = tid; p < (tile >> 1); p += SORT_THREADS) {
+                int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                cmpx(lk, li, i, i + j, ((base + i) & k) == 0);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_rows(
+    const double* __restrict__ C, int64_t ldc, const int32_t* __restrict__ order, const double* __restrict__ np_sum,
+    const double* __restrict__ seq_sum, int n, int P, uint64_t* __restrict__ skeys, uint16_t* __restrict__ sidx,
+    uint16_t* __restrict__ R, int64_t ldr)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tile = P < SORT_TILE ? P : SORT_TILE;
+    uint64_t* lk = reinterpret_cast<uint64_t*>(smem);
+    uint16_t* li = reinterpret_cast<uint16_t*>(smem + (size_t)tile * sizeof(uint64_t));
+    const int tid = threadIdx.x;
+    const int ntiles = P / tile;
+    uint64_t* gk = skeys + (size_t)blockIdx.x * (size_t)P;
+    uint16_t* gi = sidx + (size_t)blockIdx.x * (size_t)P;
+
+    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+        const int pa = order[row];
+        const double sig = np_sum[pa], rs = seq_sum[pa];
+        const double* __restrict__ crow = C + (int64_t)pa * ldc;
+        uint16_t* __restrict__ out = R + (int64_t)row * ldr;
+
+        // ---- phase 1: build keys and fully sort every tile (directions follow the global index)
+        for (int t = 0; t < ntiles; t++) {
+            const int base = t * tile;
+            for (int e = tid; e < tile; e += SORT_THREADS) {
+                int b = base + e;
+                lk[e] = b < n ? key_of(similarity(crow[order[b]], sig, rs)) : ~0ull;
+                li[e] = (uint16_t)b;
+            }
+            __syncthreads();
+            lds_stages(lk, li, tile, base, 2, tile, tid);
+            if (ntiles == 1) {
+                for (int e = tid; e < n; e += SORT_THREADS) out[n - 1 - e] = li[e];
+            } else {
+                for (int e = tid; e < tile; e += SORT_THREADS) { gk[base + e] = lk[e]; gi[base + e] = li[e]; }
+            }
+            __syncthreads();
+        }
+        // ---- merge levels above the tile size
+        for (int k = tile << 1; k <= P && ntiles > 1; k <<= 1) {
+            for (int j = k >> 1; j >= tile; j >>= 1) {
+                for (int p = tid; p < (P >> 1); p += SORT_THREADS) {
+                    int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                    cmpx(gk, gi, i, i + j, (i & k) == 0);
+                }
+                __syncthreads();
+            }
+            for (int t = 0; t < ntiles; t++) {
+                const int base = t * tile;
+                for (int e = tid; e < tile; e += SORT_THREADS) { lk[e] = gk[base + e]; li[e] = gi[base + e]; }
+                __syncthreads();
+                // remaining strides tile/2 .. 1 of level k
+                for (int j = tile >> 1; j >= 1; j >>= 1) {
+                    for (int p = tid; p < (tile >> 1); p += SORT_THREADS) {
+                        int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                        cmpx(lk, li, i, i + j, ((base + i) & k) == 0);
+                    }
+                    __syncthreads();
+                }
+                if (k == P) {
+                    for (int e = tid; e < tile; e += SORT_THREADS) {
+                        int q = base + e;
+                        if (q < n) out[n - 1 - q] = li[e];
+                    }
+                } else {
+                    for (int e = tid; e < tile; e += SORT_THREADS) { gk[base + e] = lk[e]; gi[base + e] = li[e]; }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const double* np_sum, const double* seq_sum,
+                      int n, void* scratch, uint16_t* R, int64_t ldr, hipStream_t s)
+{
+    const int P = sort_padded_size(n);
+    const int tile = P < SORT_TILE ? P : SORT_TILE;
+    const int wgs = sort_workgroups(n);
+    uint64_t* skeys = reinterpret_cast<uint64_t*>(scratch);
+    uint16_t* sidx = reinterpret_cast<uint16_t*>(skeys + (size_t)wgs * (size_t)P);
+    size_t lds = (size_t)tile * (sizeof(uint64_t) + sizeof(uint16_t));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_sort_rows, dim3(wgs), dim3(SORT_THREADS), lds, s, C, ldc, order, np_sum, seq_sum, n, P, skeys,
+                       sidx, R, ldr);
+}
+
+// rank[row][R[row][k]] = k : scatter inside LDS (2 bytes per bin), coalesced in and out.
+__global__ __launch_bounds__(1024) void k_rank_invert(const uint16_t* __restrict__ R, uint16_t* __restrict__ rank,
+                                                      int64_t ldr, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* inv = reinterpret_cast<uint16_t*>(smem);
+    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+        const uint16_t* __restrict__ r = R + (int64_t)row * ldr;
+        for (int k = threadIdx.x; k < n; k += 1024) inv[r[k]] = (uint16_t)k;
+        __syncthreads();
+        uint16_t* __restrict__ o = rank + (int64_t)row * ldr;
+        for (int b = threadIdx.x; b < n; b += 1024) o[b] = inv[b];
+        __syncthreads();
+    }
+}
+
+void launch_rank_invert(const uint16_t* R, uint16_t* rank, int64_t ldr, int n, hipStream_t s)
+{
+    size_t lds = ((size_t)n * sizeof(uint16_t) + 15) & ~(size_t)15;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_invert), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int grid = n < 1024 ? n : 1024;
+    hipLaunchKernelGGL(k_rank_invert, dim3(grid), dim3(1024), lds, s, R, rank, ldr, n);
+}
+
+__global__ __launch_bounds__(256) void k_similarity_row(const double* __restrict__ C, int64_t ldc,
+                                                        const int32_t* __restrict__ order,
+                                                        const double* __restrict__ np_sum,
+                                                        const double* __restrict__ seq_sum, int n, int row,
+                                                        double* __restrict__ out)
+{
+    int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n) return;
+    int pa = order[row];
+    out[b] = similarity(C[(int64_t)pa * ldc + order[b]], np_sum[pa], seq_sum[pa]);
+}
+
+void launch_similarity_row(const double* C, int64_t ldc, const int32_t* order, const double* np_sum,
+                           const double* seq_sum, int n, int row, double* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_similarity_row, dim3((n + 255) / 256), dim3(256), 0, s, C, ldc, order, np_sum, seq_sum, n, row,
+                       out);
+}
+
+}  // namespace hicmi

@@ -1,0 +1,88 @@
+"""HiC-Pro text inputs -> host arrays (reference loaders: scaffoldToChromosomes.py:24-98,
+duplicated in orderGenome.py:19-93).
+
+The reference fills a Python list-of-lists cell by cell (~32 bytes per cell and minutes of
+interpreter time at N >= 16k).  Here the triplet file is parsed in chunks by pandas' C tokenizer
+with ``float_precision='round_trip'`` (the same correctly rounded conversion as Python's
+``float()``, which the reference applies at S2C:83) straight into one dense fp64 array that is
+then uploaded to HBM once.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class Bin:
+    """One genomic bin as read from HiC-Pro (S2C:24-33)."""
+    __slots__ = ("ID", "chrom", "start", "stop", "bias", "rowSum")
+
+    def __init__(self, ID, chrom, start, stop, bias, rowSum):
+        self.ID = ID
+        self.chrom = chrom
+        self.start = start
+        self.stop = stop
+        self.bias = bias
+        self.rowSum = rowSum
+
+
+def initiateLoci(bedFile, biasFile, binID_dict=False):
+    """S2C:35-68 / OG:30-63: the .bed and .biases files are read line-aligned; a bias line that is
+    exactly "nan" drops the bin, one that does not parse becomes 0.0; with ``binID_dict`` only the
+    listed bin IDs are kept."""
+    bins = []
+    with open(bedFile) as bed, open(biasFile) as bias:
+        for bed_line in bed:
+            bias_line = bias.readline()
+            cols = bed_line.strip("\r").strip("\n").split("\t")
+            bid = int(cols[3])
+            if binID_dict is not False and bid not in binID_dict:
+                continue
+            text = bias_line.strip("\r").strip("\n")
+            if text == "nan":
+                continue
+            try:
+                value = float(text)
+            except Exception:
+                value = 0.
+            bins.append(Bin(bid, cols[0], int(cols[1]), int(cols[2]), value, 0.))
+    print("Genomic loci found" + "\t" + str(len(bins)))
+    return bins
+
+
+def read_contact_matrix(matrixFile, binList, chunk_lines: int = 4_000_000) -> np.ndarray:
+    """S2C:70-98: ``id1<TAB>id2<TAB>value`` triplets into a dense symmetric fp64 array in ``binList``
+    order.  Triplets naming an unknown bin are skipped; each one sets [i][j] and [j][i]; when a
+    cell is named twice the later line wins, exactly as sequential assignment would."""
+    import pandas as pd
+
+    n = len(binList)
+    ids = np.fromiter((b.ID for b in binList), dtype=np.int64, count=n)
+    max_id = int(ids.max()) if n else 0
+    lookup = np.full(max_id + 2, -1, dtype=np.int64)
+    if n:
+        if ids.min() < 0:
+            raise ValueError("negative bin ID")
+        lookup[ids] = np.arange(n)
+    mat = np.zeros((n, n), dtype=np.float64)
+    edges = 0
+    reader = pd.read_csv(matrixFile, sep="\t", header=None, names=["a", "b", "v"],
+                         dtype={"a": np.int64, "b": np.int64, "v": np.float64},
+                         float_precision="round_trip", chunksize=chunk_lines, engine="c")
+    for chunk in reader:
+        a = chunk["a"].to_numpy()
+        b = chunk["b"].to_numpy()
+        v = chunk["v"].to_numpy()
+        ok = (a >= 0) & (a <= max_id) & (b >= 0) & (b <= max_id)
+        ia = np.where(ok, lookup[np.where(ok, a, 0)], -1)
+        ib = np.where(ok, lookup[np.where(ok, b, 0)], -1)
+        ok = (ia >= 0) & (ib >= 0)
+        ia, ib, v = ia[ok], ib[ok], v[ok]
+        # interleave (i,j),(j,i) per line so that "last assignment wins" follows file order
+        rows = np.empty(2 * len(ia), dtype=np.int64)
+        cols = np.empty(2 * len(ia), dtype=np.int64)
+        rows[0::2], rows[1::2] = ia, ib
+        cols[0::2], cols[1::2] = ib, ia
+        mat[rows, cols] = np.repeat(v, 2)
+        edges += len(ia)
+    print("Edges added to adjacency matrix" + "\t" + str(edges))
+    return mat

@@ -1,0 +1,432 @@
+"""Part 1 (bins -> chromosome groups) on MI355X: drop-in for the reference module of the same name.
+
+Same ``runPipeline`` signature and intermediate files as /root/reference/HIC_ASSEMBLER/
+scaffoldToChromosomes.py (S2C below), and the same stage-function names the reference's notebook
+calls, but the N x N matrix lives in HBM behind a libhicmi context (``DeviceMatrix``) and every
+heavy step is a hand-written gfx950 kernel reached through the C ABI of include/hicmi.h:
+
+  S2C stage                                   here
+  ------------------------------------------  ------------------------------------------------
+  removeRows / row sums        S2C:100-136    hicmi_row_sums, hicmi_compact
+  convertMatrix(distance)      S2C:138-155    fused into hicmi_upgma (k_build_w)
+  squareform+average+dendrogram S2C:187-208   hicmi_upgma (k_nnchain + host label / leaf walk)
+  reorderMatrix, similarity    S2C:157-163,149 fused into hicmi_rank_matrix (k_sort_rows)
+  numpy.argsort[:, ::-1]       S2C:1132       hicmi_rank_matrix
+  find_matrix_pvalue_breakpoints S2C:413-511  hicmi_cut_scan (+ host window logic)
+  filter_noisy_breakpoints     S2C:553-727    hicmi_filter_scan (+ host control flow)
+
+Host control flow (loops over cut candidates, file formats, scaffold voting) is restated here in
+Python because its decisions are sequential and tiny.  There is no CPU fallback for the kernels.
+
+Not implemented: the HMM boundary finder, the Louvain tail
+(``modularity > 0``; unseeded-random in the reference) and PNG plotting.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from . import _lib
+from .hostio import Bin, initiateLoci, read_contact_matrix  # noqa: F401  (re-exported reference names)
+
+
+# ------------------------------------------------------------------------------------------------
+class DeviceMatrix:
+    """The contact map resident on one GPU, plus the host-side bookkeeping the reference keeps in
+    its ``numpy.matrix`` / ``binList`` pair."""
+
+    def __init__(self, ctx: _lib.Context):
+        self.ctx = ctx
+        self.kind = "contacts"         # contacts -> distance -> similarity (labels only; transforms are fused)
+        self.order = None              # current row/column order relative to the uploaded matrix
+        self.np_sum = None
+        self.seq_sum = None
+
+    @property
+    def n(self):
+        return self.ctx.n
+
+    def __len__(self):
+        return self.ctx.n
+
+
+class RankMatrix:
+    """Device-resident result of ``argsort(axis=1)[:, ::-1]`` (S2C:1132) and its inverse."""
+
+    def __init__(self, ctx: _lib.Context):
+        self.ctx = ctx
+
+    def __len__(self):
+        return self.ctx.n
+
+    def rows(self, row0=0, nrows=None):
+        return self.ctx.rank_rows(row0, nrows, inverse=False)
+
+
+def buildAdjacencyMatrix(matrixFile, binList, binID_dict=False, device=0, ctx=None):
+    """S2C:70-98: dense matrix from HiC-Pro triplets, uploaded once to HBM."""
+    host = read_contact_matrix(matrixFile, binList)
+    ctx = ctx or _lib.Context(device)
+    ctx.set_contacts(host)
+    print("Rows in adjacency matrix " + str(len(binList)))
+    return DeviceMatrix(ctx)
+
+
+def removeRows(matrix: DeviceMatrix, binList, zeroRows=True, biasVals=False):
+    """S2C:100-136: drop rows (and columns) whose NumPy row sum is 0, then store each bin's
+    left-to-right row sum.  ``biasVals`` filtering is kept for signature compatibility."""
+    np_sum, seq_sum = matrix.ctx.row_sums()
+    drop = []
+    for i in range(len(binList)):
+        if zeroRows is True and np_sum[i] == 0:
+            drop.append(i)
+            continue
+        if biasVals is not False and (binList[i].bias > biasVals[1] or binList[i].bias < biasVals[0]):
+            drop.append(i)
+    print("Rows/columns to remove " + str(len(drop)))
+    if drop:
+        gone = set(drop)
+        keep = [i for i in range(len(binList)) if i not in gone]
+        matrix.ctx.compact(keep)
+        binList = [binList[i] for i in keep]
+        np_sum, seq_sum = matrix.ctx.row_sums()
+    matrix.np_sum, matrix.seq_sum = np_sum, seq_sum
+    for b, v in zip(binList, seq_sum):
+        b.rowSum = float(v)
+    return matrix, binList
+
+
+def convertMatrix(adjacencyMatrix: DeviceMatrix, binList, distance=True, similarity=False):
+    """S2C:138-155.  The transforms are elementwise and are fused into the kernels that consume
+    them (k_build_w for distance, k_sort_rows for similarity), so this only records the stage."""
+    if distance is True:
+        adjacencyMatrix.kind = "distance"
+    elif similarity is True:
+        adjacencyMatrix.kind = "similarity"
+    return adjacencyMatrix
+
+
+def averageClusterNodes(adjacencyMatrix: DeviceMatrix, nodeLabels, noPlot=True):
+    """S2C:187-208: UPGMA + count-sorted leaf order.  Returns a dict with the two keys of SciPy's
+    dendrogram object the reference uses ('ivl', 'leaves') plus the linkage matrix 'Z'."""
+    t0 = time.time()
+    leaves, z = adjacencyMatrix.ctx.upgma(want_linkage=True)
+    print("Time to cluster " + str(time.time() - t0))
+    leaves = [int(v) for v in leaves]
+    return {"ivl": [nodeLabels[i] for i in leaves], "leaves": leaves, "Z": z}
+
+
+def dendrogramLeafOrder_toFile(dendrogramObj, outFile):
+    """S2C:210-220: ``label<TAB>leaf`` lines, no trailing newline."""
+    with open(outFile, "w") as fh:
+        fh.write("\n".join(l + "\t" + str(i) for l, i in zip(dendrogramObj["ivl"], dendrogramObj["leaves"])))
+
+
+def readDengrogramLeavesFromFile(dendrogramFile):
+    """S2C:222-234."""
+    out = {"ivl": [], "leaves": []}
+    with open(dendrogramFile) as fh:
+        for line in fh:
+            cols = line.strip("\r").strip("\n").split("\t")
+            out["ivl"].append(cols[0])
+            out["leaves"].append(int(cols[-1]))
+    return out
+
+
+def reorderMatrix(matrix: DeviceMatrix, binList, newOrder):
+    """S2C:157-163: the permutation is applied by the consuming kernel through an index vector."""
+    newOrder = [int(v) for v in newOrder]
+    base = matrix.order if matrix.order is not None else list(range(matrix.n))
+    matrix.order = [base[i] for i in newOrder]
+    return matrix, [binList[i] for i in newOrder]
+
+
+def rankOrderMatrix(matrix: DeviceMatrix) -> RankMatrix:
+    """S2C:1132 ``numpy.asarray(numpy.argsort(adjMat, axis=1)[:, ::-1])`` on the similarity matrix
+    in the current order.  Ties (undefined in the reference) resolve to the larger column first."""
+    if matrix.kind != "similarity":
+        raise ValueError("rankOrderMatrix expects the similarity stage (call convertMatrix(similarity=True))")
+    order = matrix.order if matrix.order is not None else list(range(matrix.n))
+    matrix.ctx.rank_matrix(order)
+    return RankMatrix(matrix.ctx)
+
+
+# ------------------------------------------------------------------------------------------------
+def hyper_geom(x, M, n, N):
+    """S2C:352-368 (= scipy.stats.hypergeom.sf(x-1, M, n, N)), evaluated by libhicmi."""
+    return _lib.hypergeom_sf(x, M, n, N)
+
+
+def get_sliding_window_distance_metrics(input_array, window_size, global_index=0):
+    """S2C:370-411: left-half minus right-half window sums; 0 where the right half is short."""
+    if window_size >= len(input_array):
+        return ["NA", "NA", "NA"]
+    a = np.asarray(input_array, dtype=np.int64)
+    h = int(window_size)
+    cs = np.concatenate(([0], np.cumsum(a)))
+    k = np.arange(len(a) - h)
+    ok = k + 2 * h <= len(a)
+    scores = np.zeros(len(k), dtype=np.int64)
+    kk = k[ok]
+    scores[ok] = (cs[kk + h] - cs[kk]) - (cs[kk + 2 * h] - cs[kk + h])
+    best = int(np.flatnonzero(scores == scores.max())[0])
+    return [int(v) for v in scores], h, best
+
+
+def find_matrix_pvalue_breakpoints(argsorted_mat: RankMatrix, start, min_size, world_size, psig=.05):
+    """S2C:413-511 for one ``start``.  Counts and significance flags come from the GPU
+    (hicmi_cut_scan); the >= 90 % rule that shrinks M (S2C:473-483) and the window scan run here.
+    The window-shrinking retry of S2C:499-508 cannot produce a cut (its scores are < min_size while
+    S2C:488 tests == min_size), so it is not repeated."""
+    ctx = argsorted_mat.ctx
+    M = world_size
+    loop_count = 0
+    while True:
+        sig = ctx.cut_scan(int(start), int(M), float(psig))
+        loop_count += 1
+        if (int(sig.sum()) / len(sig)) >= .9:
+            morg = M
+            M = int(M - start)
+            print("- M value (world_size) changed to dynamic {} --> {}".format(morg, M))
+        else:
+            break
+        if loop_count >= 5:
+            break
+    w = get_sliding_window_distance_metrics(sig, window_size=min_size)
+    if w[0] == "NA":
+        return [], []
+    inds = [ii + min_size for ii, v in enumerate(w[0]) if v == min_size]
+    return [min_size] * len(inds), inds
+
+
+def pre_process_all_matrix_breakpoints(argsorted_mat: RankMatrix, min_size=5, min_frac=.05, psig=.05):
+    """S2C:513-551.  As in the reference the scan tests against the literal .05 (S2C:535), not
+    the ``psig`` argument."""
+    mat_size = len(argsorted_mat)
+    stop_ind = int(mat_size - (mat_size * min_frac))
+    ind = 0
+    cinds = []
+    if min_frac == 1:
+        return cinds
+    while True:
+        _vals, pre_cut_inds = find_matrix_pvalue_breakpoints(argsorted_mat, ind, min_size, mat_size - ind, psig=.05)
+        if len(pre_cut_inds) == 0:
+            break
+        ind += pre_cut_inds[0]
+        cinds.append(ind)
+        if (ind >= stop_ind) or ((mat_size - ind) <= min_size):
+            break
+    print("- Breakpoints found {}".format(len(cinds)))
+    return cinds
+
+
+def filter_noisy_breakpoints(argsorted_mat: RankMatrix, original_inds, psig=.05):
+    """S2C:553-727.  Row tests run on the GPU (hicmi_filter_scan); the merge decisions between
+    candidate cuts are scalar hypergeometric tests evaluated by libhicmi's host code."""
+    if len(original_inds) == 0:
+        return []
+    ctx = argsorted_mat.ctx
+    n = len(argsorted_mat)
+    MD = int(n / 5)
+    MAX_ROUNDS = 10 * len(original_inds)
+    altered = [int(v) for v in original_inds]
+    prev_filtered = {}
+    while True:
+        start = 0
+        filtered = {}
+        round_count = 0
+        while True:
+            if round_count >= MAX_ROUNDS:
+                print("- WARNING - Maximum number of rounds {} exceeded".format(MAX_ROUNDS))
+                break
+            M = n - start
+            noise_found = 0
+            keep_from = 0
+            for i, c in enumerate(altered):
+                local = c - start
+                n_rows = min(n - start, MD + 1)            # rows beyond start+MD are forced to 0 (S2C:626-628)
+                flags = np.zeros(n - start, dtype=np.int64)
+                flags[:n_rows] = ctx.filter_scan(start, c, n_rows, M, float(psig))
+                sig_cuts = []
+                fc_prev = start
+                for ai_ind, ai in enumerate(altered):
+                    if ai == fc_prev:
+                        continue
+                    lo, hi = fc_prev, ai
+                    fc_prev = ai
+                    if hi <= lo:
+                        break
+                    x = int(flags[lo - start:hi - start].sum())
+                    noise_pval = hyper_geom(x, M, local, hi - lo)
+                    if noise_pval < psig:
+                        sig_cuts.append((ai_ind, ai))
+                if sig_cuts:
+                    keep_from, start = sig_cuts[-1]
+                    filtered[start] = ''
+                    noise_found = 1
+                    break
+                filtered[c] = ''
+                keep_from = i
+            round_count += 1
+            if noise_found == 0:
+                break
+            altered = altered[keep_from:]
+        if prev_filtered != filtered:
+            altered = sorted(filtered)
+            prev_filtered = filtered
+        else:
+            break
+    out = sorted(filtered.keys())
+    print("- Original cut indices {}".format(list(original_inds)))
+    print("- Filtered cut indices {}".format(out))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def writeBinGroupingsToFile(coords, binList, outFile):
+    """S2C:945-964."""
+    bounds = [0] + [int(c) for c in coords] + [len(binList)]
+    with open(outFile, "w") as fh:
+        for g in range(len(bounds) - 1):
+            fh.write("### Chromosome group " + str(g + 1) + " ###\n")
+            for b in binList[bounds[g]:bounds[g + 1]]:
+                fh.write("\t".join((str(b.ID), b.chrom, str(b.start), str(b.stop), str(b.bias))) + "\n")
+
+
+def readSizeFileToDict(sizeFile):
+    """S2C:968-979."""
+    sizes = {}
+    with open(sizeFile) as fh:
+        for line in fh:
+            cols = line.strip("\r").strip("\n").split("\t")
+            sizes[cols[0]] = int(cols[1])
+    return sizes
+
+
+def readBinGroupingsFromFile(binGroupingsFile):
+    """S2C:981-999: first line skipped unconditionally, every later '#' line starts a new group."""
+    groups, cur = [], []
+    with open(binGroupingsFile) as fh:
+        fh.readline()
+        for line in fh:
+            line = line.strip("\n").strip("\r")
+            if line[0] != "#":
+                cur.append(line)
+            else:
+                groups.append(cur)
+                cur = []
+    groups.append(cur)
+    print(str(len(groups)) + " chromosomes read in from file")
+    return groups
+
+
+def assessClusterList(cList, scaffDict, outFile, percentToAssign=51.):
+    """S2C:1001-1036: a scaffold joins the group holding >= 51 % of its bins and brings ALL its bins."""
+    members = {}
+    for line in cList:
+        cols = line.split("\t")
+        members.setdefault(cols[1], []).append(int(cols[0]))
+    final, assigned, false_pos = [], 0, 0
+    outFile.write("#Scaffold\tNodesAssigend\tTotalNodes\tAssigned%\n")
+    for s, nodes in members.items():
+        have, total = len(nodes), len(scaffDict[s])
+        pct = round(((float(have) / float(total)) * 100.), 2)
+        outFile.write(str(s) + "\t" + str(have) + "\t" + str(total) + "\t" + str(pct) + "%\n")
+        if pct >= percentToAssign:
+            final += scaffDict[s]
+            assigned += 1
+        else:
+            false_pos += have
+    outFile.write("Total scaffolds clustered to chromosome " + str(len(members)) + "\n")
+    outFile.write("Total scaffolds assigned to chromosome " + str(assigned) + "\n")
+    return final, false_pos, assigned
+
+
+def assessChromosomeClustering(chromList, statsFile, percentToAssign=51.):
+    """S2C:1038-1077."""
+    all_nodes = [line for grp in chromList for line in grp]
+    scaffolds = {}
+    for line in all_nodes:
+        cols = line.split("\t")
+        scaffolds.setdefault(cols[1], []).append([int(cols[0]), cols[1]])
+    for s in scaffolds:
+        scaffolds[s] = sorted(scaffolds[s], key=lambda e: e[0])
+    final, false_pos, assigned = [], 0, 0
+    with open(statsFile, "w") as fh:
+        for k, grp in enumerate(chromList):
+            fh.write("### Chromosome" + str(k + 1) + " ###\n")
+            nodes, fp, na = assessClusterList(grp, scaffolds, fh, percentToAssign=percentToAssign)
+            if len(nodes) > 0:
+                final.append(nodes)
+            false_pos += fp
+            assigned += na
+            fh.write("####################\n")
+        total = len(all_nodes)
+        fh.write("Total Nodes " + str(total) + "\n")
+        fh.write("Properly clustered nodes " + str(total - false_pos) + "\n")
+        fh.write("Falsely clustered nodes " + str(false_pos) + "\n")
+        fh.write("Total scaffolds assigned to chromosomes " + str(assigned) + "\n")
+        fh.write("Error rate ~" + str(round((float(false_pos) / float(total)) * 100., 2)) + "%\n")
+    return final
+
+
+def writeChromosomeGroupingsToFile(chromList, scaffSizeDict, outFile):
+    """S2C:1079-1100: groups ordered by total scaffold bp, largest first (stable)."""
+    sizes = [sum(scaffSizeDict[s] for s in {e[1]: '' for e in grp}) for grp in chromList]
+    ranked = sorted(range(len(chromList)), key=lambda k: sizes[k], reverse=True)
+    with open(outFile, "w") as fh:
+        for new_id, k in enumerate(ranked):
+            fh.write("### Chromosome group " + str(new_id + 1) + " ###\n")
+            for e in chromList[k]:
+                fh.write(str(e[0]) + "\t" + str(e[1]) + "\n")
+
+
+# ------------------------------------------------------------------------------------------------
+def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, hicProScaffSizeFile,
+                dendrogramOrderFile, avgClusterPlot, avgClusterPlot_outlined,
+                binGroupFile, assessmentFile, chromosomeGroupFile,
+                hyperGeom, hmm, minSize, modularity, louvainRounds,
+                psig, convergenceRounds, lookAhead, resolution, device=0):
+    """S2C:1104-1174, same positional arguments (``device`` is an optional extra)."""
+    print("########################################")
+    print("### Working on Part1 of the pipeline ###")
+    t_all = time.time()
+    if hyperGeom is not True:
+        raise NotImplementedError("only the hyperGeom = True strategy is implemented on MI355X "
+                                  "(hmm needs hmmlearn's stochastic EM; SURVEY.md section 2 row 7)")
+    if modularity is not False and modularity > 0.0:
+        raise NotImplementedError("modularity > 0 (Louvain tail, unseeded random in the reference, S2C:253) "
+                                  "is not implemented: set `modularity = 0`")
+    t0 = time.time()
+    binList = initiateLoci(hicProBedFile, hicProBiasFile)
+    adjMat = buildAdjacencyMatrix(hicProMatrixFile, binList, device=device)
+    try:
+        adjMat, binList = removeRows(adjMat, binList, zeroRows=True, biasVals=False)
+        adjMat = convertMatrix(adjMat, binList, distance=True, similarity=False)
+        dendroLabels = [b.chrom + '_' + str(b.ID) for b in binList]
+        dendrogram = averageClusterNodes(adjMat, dendroLabels, noPlot=True)
+        dendrogramLeafOrder_toFile(dendrogram, dendrogramOrderFile)
+        dendoLeaves = readDengrogramLeavesFromFile(dendrogramOrderFile)
+        adjMat, binList = reorderMatrix(adjMat, binList, dendoLeaves['leaves'])
+        print("- plotting is not part of the MI355X hot path: " + str(avgClusterPlot) + " not written")
+        print("Total run-time to cluster = " + str(time.time() - t0))
+        t0 = time.time()
+        adjMat = convertMatrix(adjMat, binList, distance=False, similarity=True)
+        argsorted_adjMat = rankOrderMatrix(adjMat)
+        initial_cut_inds = pre_process_all_matrix_breakpoints(argsorted_adjMat, min_size=minSize,
+                                                              min_frac=modularity, psig=psig)
+        cutIndices = filter_noisy_breakpoints(argsorted_adjMat, initial_cut_inds, psig=psig)
+    finally:
+        adjMat.ctx.close()
+    writeBinGroupingsToFile(cutIndices, binList, binGroupFile)
+    print("Total run-time to identify chromosome boundaries = " + str(time.time() - t0))
+    t0 = time.time()
+    fastaSizeDict = readSizeFileToDict(hicProScaffSizeFile)
+    binGroups = readBinGroupingsFromFile(binGroupFile)
+    chrGroups = assessChromosomeClustering(binGroups, assessmentFile)
+    writeChromosomeGroupingsToFile(chrGroups, fastaSizeDict, chromosomeGroupFile)
+    print("Total run-time to assign scaffolds to chromosomes = " + str(time.time() - t0))
+    print("Total run-time of Part1 = " + str(time.time() - t_all))
+    print("CutIndices = " + str(cutIndices))
+    print("- Part 1 (grouping bins to groups) completed successfully")

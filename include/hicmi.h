@@ -1,0 +1,135 @@
+/*
+ * hicmi.h - C ABI of libhicmi.so: the MI355X (gfx950) hot path of Hi-C contact-map clustering
+ * (Part 1) and scaffold ordering (Part 2).
+ *
+ * The reference (AO33/HiC_Genome_Assembler) is pure Python and has no FFI of its own
+ * (SURVEY.md section 8b); the boundary a maintainer would bind is therefore defined here, one entry
+ * point per native routine the reference reaches through NumPy / SciPy / Numba.  Each
+ * declaration cites the reference call site it replaces (paths relative to
+ * HIC_ASSEMBLER/; S2C = scaffoldToChromosomes.py, OG = orderGenome.py).  INTEGRATION.md shows
+ * the ctypes stub for each.
+ *
+ * Conventions: every function returns 0 on success and a negative HICMI_E* code on failure;
+ * hicmi_last_error() returns a message for the calling thread.  Host buffers are caller-owned,
+ * plain pointers and sizes only.  A context belongs to one host thread and one GPU; all work
+ * is issued on the context's own HIP stream and every call that returns host data has
+ * synchronised that stream before returning.  Matrices are row-major.
+ *
+ * There is NO CPU fallback anywhere in this library: without a HIP device hicmi_create fails.
+ */
+#ifndef HICMI_H
+#define HICMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HICMI_ABI_VERSION 1
+
+#define HICMI_OK            0
+#define HICMI_EINVAL       -1   /* bad argument / call order */
+#define HICMI_EHIP         -2   /* HIP runtime error (message has the hipError string) */
+#define HICMI_ENOMEM       -3
+#define HICMI_ESTATE       -4   /* kernel reported an internal inconsistency (e.g. nn-chain guard) */
+#define HICMI_EUNSUPPORTED -5   /* e.g. more than 65536 bins (rank matrix is uint16 in this version) */
+
+typedef struct hicmi_ctx hicmi_ctx;
+
+int         hicmi_abi_version(void);
+const char *hicmi_last_error(void);
+int         hicmi_device_count(int *count);
+
+/* One context per GPU / per process rank. */
+int hicmi_create(int device, hicmi_ctx **out);
+int hicmi_destroy(hicmi_ctx *ctx);
+/* The HIP stream all kernels of this context are launched on (hipStream_t as void*), so a caller
+ * can bracket launches with its own events. */
+int hicmi_stream(hicmi_ctx *ctx, void **stream_out);
+int hicmi_synchronize(hicmi_ctx *ctx);
+
+/* ---- contact matrix -------------------------------------------------------------------------
+ * Replaces the dense fp64 matrix built by buildAdjacencyMatrix (S2C:70-98, OG:65-93).
+ * _host copies n*n doubles to the GPU; _device adopts a caller-owned device allocation (leading
+ * dimension ld >= n, in elements) without copying - the caller keeps it alive and unchanged. */
+int hicmi_set_contacts_host(hicmi_ctx *ctx, const double *contacts, int64_t n);
+int hicmi_set_contacts_device(hicmi_ctx *ctx, const double *d_contacts, int64_t n, int64_t ld);
+
+/* Row sums, both flavours the reference uses:
+ *   np_sum[i]  = row.sum() as NumPy reduces it (pairwise, 8192-element chunks)   S2C:112, S2C:147
+ *   seq_sum[i] = builtin sum() left to right                                     S2C:134
+ * Either output may be NULL.  Results are also kept on the device for the later stages. */
+int hicmi_row_sums(hicmi_ctx *ctx, double *np_sum, double *seq_sum);
+
+/* removeRows (S2C:100-136): keep only rows/columns keep[0..n_keep) (ascending); recomputes both
+ * row sums on the compacted matrix.  Only valid for a matrix set with hicmi_set_contacts_host. */
+int hicmi_compact(hicmi_ctx *ctx, const int32_t *keep, int64_t n_keep);
+
+/* ---- Part 1: clustering ---------------------------------------------------------------------
+ * convertMatrix(distance) + squareform + scipy average + dendrogram leaf order
+ * (S2C:138-155, S2C:187-208).  Z_out: (n-1) x 4 doubles in SciPy's linkage convention (may be
+ * NULL); leaves_out: n int32 (dendrogram(count_sort='ascending')['leaves']). */
+int hicmi_upgma(hicmi_ctx *ctx, double *Z_out, int32_t *leaves_out);
+
+/* reorderMatrix + convertMatrix(similarity) + numpy.argsort(axis=1)[:, ::-1]
+ * (S2C:157-163, S2C:149, S2C:1132) for the row/column order `order` (n int32, normally the leaves).
+ * Builds, on the device, R[a][k] = column with the k-th largest similarity in row a (ties:
+ * larger column index first) and its inverse rank[a][b] = position of column b in row a. */
+int hicmi_rank_matrix(hicmi_ctx *ctx, const int32_t *order);
+/* Copy rows [row0, row0+nrows) of R (or of its inverse when inverse != 0) to the host as uint16. */
+int hicmi_get_rank_rows(hicmi_ctx *ctx, int64_t row0, int64_t nrows, int inverse, uint16_t *out);
+/* Similarity values of one reordered row (S2C:149), for tests. */
+int hicmi_get_similarity_row(hicmi_ctx *ctx, int64_t row, double *out);
+
+/* ---- Part 1: hypergeometric cut scan ---------------------------------------------------------
+ * find_matrix_pvalue_breakpoints inner loop (S2C:449-469) for one `start`:
+ *   x[i-start] = #{ v in R[i][0 : i-start] : start <= v <= i }           for i in (start, n)
+ *   sig[i-start] = 0 if hyper_geom(x, M, i-start, i-start) >= psig else 1   (NaN counts as 1)
+ * and x[0] = sig[0] = 0 (S2C:448-452).  x_out / sig_out hold n-start entries; either may be NULL.
+ * The counts of the last `start` are cached, so the M-rescan of S2C:473-477 costs no matrix pass. */
+int hicmi_cut_scan(hicmi_ctx *ctx, int64_t start, int64_t M, double psig, int32_t *x_out, uint8_t *sig_out);
+
+/* filter_noisy_breakpoints row tests (S2C:622-636) for one (start, c):
+ *   rows ii in [start, start+n_rows):  x = #{ v in R[ii][0 : c-start] : start <= v <= c }
+ *   sig = 1 if hyper_geom(x, M, c-start, c-start) < psig else 0            (NaN counts as 0) */
+int hicmi_filter_scan(hicmi_ctx *ctx, int64_t start, int64_t c, int64_t n_rows, int64_t M, double psig,
+                      int32_t *x_out, uint8_t *sig_out);
+
+/* hyper_geom (S2C:352-368) = scipy.stats.hypergeom.sf(x-1, M, n, N); NaN for invalid arguments.
+ * Host-side scalar evaluation with the same code the kernels run. */
+double hicmi_hypergeom_sf(int64_t x, int64_t M, int64_t n, int64_t N);
+
+/* Host helpers that finish scipy's linkage: stable sort of raw merges by height + union-find
+ * relabel, and the count-sorted leaf walk.  Exposed for tests. */
+int hicmi_label_linkage(const double *Zraw, int64_t n, double *Z_out);
+int hicmi_leaf_order(const double *Z, int64_t n, int32_t *leaves_out);
+/* Raw merges (x, y, height, size) in nn-chain merge order from the last hicmi_upgma. */
+int hicmi_get_raw_merges(hicmi_ctx *ctx, double *Zraw_out);
+
+/* ---- Part 2: ordering objective --------------------------------------------------------------
+ * giveNewAdjMat (OG:296-308): select the sub-matrix of the context's contact matrix for the bins
+ * sel[0..n) (indices into the contact matrix); later candidates index into this selection. */
+int hicmi_p2_select(hicmi_ctx *ctx, const int32_t *sel, int64_t n);
+/* total = sum of all entries above the diagonal of the selected sub-matrix (OG:343,448,506). */
+int hicmi_p2_total(hicmi_ctx *ctx, double *total_out);
+/* costFunction_numba (OG:184-191) of n_cand candidate orders at once.  perms: n_cand x n_used
+ * int32 positions into the current selection (the reference's nOrder lists, OG:347,357,460,532);
+ * n_used <= selection size.  scores_out: n_cand doubles.  Identical index lists give bit-identical
+ * scores. */
+int hicmi_p2_score(hicmi_ctx *ctx, const int32_t *perms, int64_t n_cand, int64_t n_used, double total,
+                   double *scores_out);
+
+/* ---- timing ----------------------------------------------------------------------------------
+ * Accumulated device time (HIP events on the context stream) per kernel family since the last
+ * reset, for bench.py's roofline object.  names_out: caller buffer receiving ';'-separated names;
+ * ms_out / launches_out / bytes_out: one entry per name (algorithmic bytes as defined in DESIGN.md). */
+int hicmi_timing_reset(hicmi_ctx *ctx);
+int hicmi_timing_enable(hicmi_ctx *ctx, int on);
+int hicmi_timing_get(hicmi_ctx *ctx, char *names_out, int64_t names_cap, double *ms_out,
+                     int64_t *launches_out, double *bytes_out, int64_t cap, int64_t *count_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HICMI_H */

@@ -1,0 +1,324 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every C-ABI stage of libhicmi against the CPU
+oracle on the same inputs, against the reference-generated fixtures in tests/golden/, and - at the
+BASELINE.json sizes - through size-independent properties.  Integer/byte outputs and the fp64
+Part 1 intermediates must be bit-exact; ordering scores are compared at 1e-10 relative (the
+north-star tolerance is 1e-5; the kernel is fp64 with a different summation order than
+numpy.trace's pairwise sums)."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["n160", "n300_edges", "n400_default", "n600", "n2000"]
+
+
+@pytest.fixture(scope="module")
+def hic():
+    from hic_genome_assembler_amd import _lib
+    _lib.load()
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def orc():
+    import hic_oracle
+    return hic_oracle
+
+
+# --------------------------------------------------------------------------------- row sums
+@pytest.mark.parametrize("n", [1, 7, 129, 600, 2049, 8200, 16390])
+def test_row_sums_bit_exact(hic, orc, n):
+    rng = np.random.default_rng(n)
+    rows = min(n, 300)
+    m = np.zeros((n, n))
+    m[:rows] = rng.random((rows, n)) * 1000.0
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(m)
+        np_sum, seq = ctx.row_sums()
+    assert np.array_equal(np_sum[:rows], orc.np_row_sums(m[:rows]))
+    assert np.array_equal(seq[:rows], orc.seq_row_sums(m[:rows]))
+    assert np.all(np_sum[rows:] == 0) and np.all(seq[rows:] == 0)
+
+
+def test_compact_drops_rows_and_columns(hic, orc):
+    rng = np.random.default_rng(3)
+    m = rng.random((50, 50)); m = m + m.T
+    keep = np.array([i for i in range(50) if i not in (3, 17, 49)], dtype=np.int32)
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(m)
+        ctx.compact(keep)
+        np_sum, seq = ctx.row_sums()
+    sub = np.ascontiguousarray(m[np.ix_(keep, keep)])
+    assert np.array_equal(np_sum, orc.np_row_sums(sub))
+    assert np.array_equal(seq, orc.seq_row_sums(sub))
+
+
+# --------------------------------------------------------------------------------- UPGMA
+def _upgma_both(hic, orc, contacts):
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(contacts)
+        leaves, z = ctx.upgma()
+        zraw = ctx.raw_merges()
+    dist = orc.to_distance(contacts)
+    zraw_o = orc.nn_chain_raw(dist)
+    leaves_o, z_o = orc.average_cluster_leaves(dist)
+    return leaves, z, zraw, leaves_o, z_o, zraw_o
+
+
+@pytest.mark.parametrize("n,seed", [(2, 0), (3, 1), (17, 2), (64, 3), (65, 4), (333, 5), (1025, 6), (2500, 7)])
+def test_upgma_random_bit_exact(hic, orc, n, seed):
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, n)) + 0.01
+    c = c + c.T                                  # contacts symmetric; distance is still asymmetric (row sums differ)
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, c)
+    assert np.array_equal(zraw, zraw_o)          # merge order, pairs, heights, sizes: bit for bit
+    assert np.array_equal(z, z_o)
+    assert np.array_equal(leaves, leaves_o)
+
+
+def test_upgma_heavy_ties_bit_exact(hic, orc):
+    rng = np.random.default_rng(11)
+    c = rng.integers(1, 4, size=(200, 200)).astype(np.float64)
+    c = np.triu(c, 1) + np.triu(c, 1).T + np.eye(200)
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, c)
+    assert np.array_equal(zraw, zraw_o)
+    assert np.array_equal(leaves, leaves_o)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_upgma_matches_reference_linkage(hic, name):
+    spec, meta, gold, lay, c = gc.load_case(name)
+    nan_bins = set(spec.get("nan_bias", ()))
+    keep = np.array([i for i in np.flatnonzero(c.sum(axis=1) != 0) if i not in nan_bins])
+    sub = np.ascontiguousarray(c[np.ix_(keep, keep)])
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(sub)
+        leaves, z = ctx.upgma()
+    assert np.array_equal(z, gold["Z"])          # scipy.cluster.hierarchy.average as run by the reference
+    ref_leaves = [int(l.split("\t")[1]) for l in gc.golden_text(name, "dendrogramOrder.txt").split("\n")]
+    assert list(leaves) == ref_leaves
+
+
+# --------------------------------------------------------------------------------- rank matrix
+def _oracle_rank(orc, contacts, order):
+    bins = [orc.Bin(i, "s", 0, 0, 0.0, 0.0) for i in range(len(contacts))]
+    mat, bins = orc.remove_zero_rows(contacts.copy(), bins)
+    dist = orc.to_distance(mat)
+    dist = dist[:, order][order]
+    bins = [bins[i] for i in order]
+    sim = orc.to_similarity(dist, bins)
+    return sim, orc.rank_order(sim)
+
+
+@pytest.mark.parametrize("n,seed", [(2, 0), (100, 1), (1000, 2), (3000, 3), (8192, 4), (9001, 5)])
+def test_rank_matrix_bit_exact(hic, orc, n, seed):
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, n)) + 0.01
+    c = c + c.T
+    order = rng.permutation(n)
+    rows = np.unique(np.concatenate([np.arange(min(n, 40)), rng.integers(0, n, 40), [n - 1]]))
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(c)
+        ctx.rank_matrix(order)
+        R = ctx.rank_rows()
+        inv = ctx.rank_rows(inverse=True)
+        srow = ctx.similarity_row(int(rows[0]))
+    sim, R_o = _oracle_rank(orc, c, order)
+    assert np.array_equal(srow, sim[rows[0]])
+    assert np.array_equal(R.astype(np.int64), R_o)
+    ar = np.arange(n)
+    for r in rows:
+        assert np.array_equal(inv[r][R[r]], ar)
+
+
+def test_rank_matrix_tie_rule(hic, orc):
+    """Heavy ties: descending value, equal values by descending column (= numpy stable argsort reversed)."""
+    rng = np.random.default_rng(21)
+    n = 700
+    c = rng.integers(0, 5, size=(n, n)).astype(np.float64)
+    c = np.triu(c, 1) + np.triu(c, 1).T + np.eye(n) * 3
+    order = rng.permutation(n)
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(c)
+        ctx.rank_matrix(order)
+        R = ctx.rank_rows()
+    _sim, R_o = _oracle_rank(orc, c, order)
+    assert np.array_equal(R.astype(np.int64), R_o)
+
+
+# --------------------------------------------------------------------------------- cut scans
+@pytest.mark.parametrize("name", ["n160", "n600"])
+def test_cut_and_filter_scans_match_oracle(hic, orc, name):
+    from scipy.stats import hypergeom
+    spec, meta, gold, lay, c = gc.load_case(name)
+    n = len(c)
+    rng = np.random.default_rng(5)
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(c)
+        leaves, _z = ctx.upgma()
+        ctx.rank_matrix(leaves)
+        R = ctx.rank_rows().astype(np.int64)
+        for start in [0, 1, 7, n // 3, n - 2, n - 1]:
+            for M in [n - start, max(1, (n - start) // 2), 3]:
+                sig, x = ctx.cut_scan(start, M, 0.05, want_x=True)
+                x_o = orc.first_pass_counts(R, start)[start:]
+                assert np.array_equal(x, x_o)
+                L = np.arange(1, n - start)
+                with np.errstate(all="ignore"):
+                    p = hypergeom.sf(x_o[1:] - 1, M, L, L)
+                sig_o = np.concatenate(([0], np.where(p >= 0.05, 0, 1)))
+                assert np.array_equal(sig, sig_o)
+        for _ in range(12):
+            start = int(rng.integers(0, n - 2))
+            cut = int(rng.integers(start, n))
+            n_rows = int(rng.integers(1, n - start + 1))
+            M = n - start
+            sig, x = ctx.filter_scan(start, cut, n_rows, M, 0.01, want_x=True)
+            sub = R[start:start + n_rows, :cut - start]
+            x_o = np.count_nonzero((sub >= start) & (sub <= cut), axis=1)
+            assert np.array_equal(x, x_o)
+            with np.errstate(all="ignore"):
+                p = hypergeom.sf(x_o - 1, M, cut - start, cut - start)
+            assert np.array_equal(sig, np.where(p < 0.01, 1, 0))
+
+
+def test_hypergeom_decisions_match_scipy(hic):
+    from scipy.stats import hypergeom
+    rng = np.random.default_rng(0)
+    for _ in range(4000):
+        M = int(rng.integers(1, 64000)); n = int(rng.integers(0, M + 1)); N = int(rng.integers(0, M + 1))
+        mean = n * N / M
+        sd = max(1.0, (mean * (1 - n / M) * (M - N) / max(M - 1, 1)) ** 0.5)
+        x = int(round(mean + rng.normal() * 3 * sd))
+        mine = hic.hypergeom_sf(x, M, n, N)
+        ref = float(hypergeom.sf(x - 1, M, n, N))
+        assert (mine < 0.05) == (ref < 0.05)
+        if ref > 1e-300:
+            assert abs(mine - ref) <= 1e-10 * ref
+    assert np.isnan(hic.hypergeom_sf(3, 10, 11, 5)) and np.isnan(hic.hypergeom_sf(3, 0, 0, 0))
+
+
+# --------------------------------------------------------------------------------- Part 2 objective
+def test_p2_scores_match_literal_cost(hic, orc):
+    rng = np.random.default_rng(8)
+    n = 260
+    m = rng.random((n, n)); m = m + m.T
+    sel = rng.permutation(n)[:200].astype(np.int32)
+    perms = np.stack([rng.permutation(200) for _ in range(64)]).astype(np.int32)
+    perms[1] = perms[0]                                  # identical index lists -> identical scores
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(m)
+        ctx.p2_select(sel)
+        total = ctx.p2_total()
+        scores = ctx.p2_score(perms, total)
+        short = ctx.p2_score(perms[:, :50] % 50, total)
+    L = orc.lib()
+    ident = np.arange(200, dtype=np.int32)
+    sub = np.ascontiguousarray(m[np.ix_(sel, sel)])
+    total_o = L.hio_total_upper(orc._dp(sub), 200, orc._ip(ident), 200)
+    assert total == pytest.approx(total_o, rel=1e-12)
+    for k in range(64):
+        ref = L.hio_cost_literal(orc._dp(sub), 200, orc._ip(perms[k]), 200, total)
+        assert scores[k] == pytest.approx(ref, rel=1e-10)
+    assert scores[0] == scores[1]
+    assert short.shape == (64,)
+
+
+# --------------------------------------------------------------------------------- end to end
+def _run_product(name, tmp_path, record=None):
+    from hic_genome_assembler_amd import scaffoldToChromosomes as p1, orderGenome as p2
+    spec = gc.load_case(name)[0]
+    paths = gc.write_case_files(name, str(tmp_path))
+    out = str(tmp_path)
+    f = lambda k: os.path.join(out, k)  # noqa: E731
+    p1.runPipeline(paths["hicProBedFile"], paths["hicProBiasFile"], paths["hicProMatrixFile"],
+                   paths["hicProScaffSizeFile"], f("dendrogramOrder.txt"), f("a.png"), f("b.png"),
+                   f("binGroups.txt"), f("assessment.txt"), f("chromosomeGroups.txt"),
+                   True, False, spec["min_size"], 0.0, 20, spec["psig"], 5, .2, 100000)
+    orig = p2.SubMatrix.scores
+    if record is not None:
+        def rec_scores(self, perms):
+            s = orig(self, perms)
+            record.extend(float(v) for v in s)
+            return s
+        p2.SubMatrix.scores = rec_scores
+    try:
+        p2.runPipeline(paths["hicProBedFile"], paths["hicProBiasFile"], paths["hicProMatrixFile"],
+                       f("chromosomeGroups.txt"), f("chromosomeOrders.txt"), out, "synthetic", f("g.png"),
+                       "synthetic genome", f("plotOrder.txt"), spec["n_scaffolds"], spec["scan_scaffolds"], 100000)
+    finally:
+        p2.SubMatrix.scores = orig
+    return out
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_pipeline_files_identical_to_reference(hic, name, tmp_path):
+    """-part1 -part2 through the drop-in modules: every output file byte-identical to what the
+    reference wrote for the same inputs, and every objective value it evaluated reproduced."""
+    spec, meta, gold, lay, c = gc.load_case(name)
+    scores = []
+    out = _run_product(name, tmp_path, record=scores)
+    for fn in gc.OUTPUT_FILES:
+        with open(os.path.join(out, fn)) as fh:
+            assert fh.read() == gc.golden_text(name, fn), fn
+    ref = gold["costs"]
+    assert len(scores) == len(ref)
+    got = np.array(scores)
+    ok = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), ok)
+    assert np.max(np.abs(got[ok] - ref[ok]) / np.abs(ref[ok])) < 1e-10
+
+
+def test_cli_drop_in(hic, tmp_path):
+    from hic_genome_assembler_amd import run_hicAssembler, synth
+    name = "n160"
+    spec, meta, gold, lay, c = gc.load_case(name)
+    paths = gc.write_case_files(name, str(tmp_path))
+    cfg = synth.write_config(str(tmp_path / "config.txt"), paths, str(tmp_path / "out"), str(tmp_path / "plots"),
+                             lay.resolution, min_size=spec["min_size"], modularity=0.0, psig=spec["psig"],
+                             n_scaffolds=spec["n_scaffolds"], scan_scaffolds=spec["scan_scaffolds"])
+    run_hicAssembler.main(["-part1", "-part2", "-c", cfg])
+    for fn in gc.OUTPUT_FILES:
+        with open(str(tmp_path / "out" / fn)) as fh:
+            assert fh.read() == gc.golden_text(name, fn), fn
+
+
+# --------------------------------------------------------------------------------- BASELINE sizes: properties
+@pytest.mark.parametrize("n", [16000])
+def test_full_size_properties(hic, n):
+    import torch
+    from hic_genome_assembler_amd import synth
+    lay = synth.make_layout(n, seed=1)
+    dev = torch.device("cuda:0")
+    c = synth.dense_contacts_torch(lay, dev, seed=1, sinkhorn_iters=8)
+    torch.cuda.synchronize()
+    with hic.Context(0) as ctx:
+        ctx.set_contacts_device(c.data_ptr(), n, keepalive=c)
+        np_sum, seq = ctx.row_sums()
+        t_sum = c.sum(dim=1).cpu().numpy()
+        assert np.allclose(np_sum, t_sum, rtol=1e-12) and np.allclose(seq, t_sum, rtol=1e-12)
+        leaves, z = ctx.upgma()
+        assert sorted(leaves.tolist()) == list(range(n))                       # a permutation
+        assert np.all(np.diff(z[:, 2]) >= 0)                                   # heights sorted
+        assert z[-1, 3] == n and np.all(z[:, 0] < z[:, 1])
+        assert np.all(z[:, 3] >= 2)
+        # planted chromosomes come out as contiguous runs of the leaf order
+        chrom = lay.chrom_of_bin[leaves]
+        assert np.count_nonzero(np.diff(chrom) != 0) == len(set(chrom.tolist())) - 1
+        ctx.rank_matrix(leaves)
+        for r in [0, 1, n // 2, n - 1]:
+            R = ctx.rank_rows(r, 1)[0].astype(np.int64)
+            inv = ctx.rank_rows(r, 1, inverse=True)[0].astype(np.int64)
+            s = ctx.similarity_row(r)
+            assert sorted(R.tolist()) == list(range(n))
+            assert np.all(np.diff(s[R]) <= 0)                                  # descending similarity
+            assert np.array_equal(inv[R], np.arange(n))
+        sig, x = ctx.cut_scan(0, n, 0.05, want_x=True)
+        for i in [1, 2, 1000, n - 1]:
+            R = ctx.rank_rows(i, 1)[0].astype(np.int64)
+            pr = R[:i]
+            assert x[i] == np.count_nonzero((pr >= 0) & (pr <= i))

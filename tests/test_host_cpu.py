@@ -1,0 +1,139 @@
+"""CPU-only tests of the host side: C-ABI surface, config parser, enumeration order, loaders."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_cases as gc
+import hic_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from hic_genome_assembler_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    with open(os.path.join(ROOT, "include", "hicmi.h")) as fh:
+        text = fh.read()
+    declared = set(re.findall(r"\b(hicmi_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 25
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (hicmi_[a-z0-9_]+)", out))
+    assert declared <= exported, sorted(declared - exported)
+    assert declared == set(lib.SIGNATURES), sorted(declared ^ set(lib.SIGNATURES))
+    assert lib.load().hicmi_abi_version() == 1
+
+
+def test_no_device_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(lib.HicmiError):
+        lib.Context(0)
+
+
+def test_host_hypergeom_matches_scipy(lib):
+    from scipy.stats import hypergeom
+    assert lib.hypergeom_sf(8, 600, 50, 50) == pytest.approx(0.045750386176022624, rel=1e-12)
+    assert lib.hypergeom_sf(7, 600, 50, 50) == pytest.approx(0.11023306317208498, rel=1e-12)
+    rng = np.random.default_rng(1)
+    for _ in range(3000):
+        M = int(rng.integers(1, 40000)); L = int(rng.integers(1, M + 1))
+        mean = L * L / M
+        sd = max(1.0, (mean * (1 - L / M) * (M - L) / max(M - 1, 1)) ** 0.5)
+        x = int(round(mean + rng.normal() * 2.5 * sd))
+        mine, ref = lib.hypergeom_sf(x, M, L, L), float(hypergeom.sf(x - 1, M, L, L))
+        assert (mine < .05) == (ref < .05) and (mine >= .05) == (ref >= .05)
+        if ref > 1e-290:
+            assert abs(mine - ref) <= 1e-10 * ref
+    # argument checking as SciPy: invalid -> NaN, below support -> 1, above -> 0
+    assert np.isnan(lib.hypergeom_sf(1, 5, 6, 2)) and np.isnan(lib.hypergeom_sf(1, -3, 0, 0))
+    assert lib.hypergeom_sf(0, 10, 4, 4) == 1.0 and lib.hypergeom_sf(5, 10, 4, 4) == 0.0
+
+
+def test_linkage_helpers_match_oracle(lib):
+    import ctypes
+    L = lib.load()
+    rng = np.random.default_rng(2)
+    for n in (2, 3, 50, 400):
+        d = rng.random((n, n)) + 1
+        zraw = orc.nn_chain_raw(d)
+        z_o = orc.label_linkage(zraw, n)
+        leaves_o = orc.leaf_order(z_o, n)
+        z = np.zeros_like(zraw)
+        assert L.hicmi_label_linkage(zraw.ctypes.data_as(ctypes.c_void_p), n, z.ctypes.data_as(ctypes.c_void_p)) == 0
+        leaves = np.zeros(n, np.int32)
+        assert L.hicmi_leaf_order(z.ctypes.data_as(ctypes.c_void_p), n, leaves.ctypes.data_as(ctypes.c_void_p)) == 0
+        assert np.array_equal(z, z_o) and np.array_equal(leaves, leaves_o)
+
+
+def test_enumeration_order_matches_oracle():
+    from hic_genome_assembler_amd import orderGenome as p2
+    for k in range(1, 7):
+        names = ["s%d" % i for i in range(k)]
+        assert p2.removeReverseDuplicates(p2.permutations(list(names), [], 0)) == \
+            orc.remove_reverse_duplicates(orc.swap_permutations(names))
+        assert p2.plusMinusPerms(names) == orc.plus_minus_perms(k)
+    assert p2.calcPossiblePerms(6) == 23040
+
+
+def test_config_parser(tmp_path):
+    from hic_genome_assembler_amd import run_hicAssembler as run, synth
+    paths = {k: "/data/" + k for k in ("hicProBedFile", "hicProBiasFile", "hicProMatrixFile", "hicProScaffSizeFile")}
+    cfg = synth.write_config(str(tmp_path / "c.txt"), paths, str(tmp_path / "o"), str(tmp_path / "p"), 100000,
+                             modularity=0.0, psig=0.01)
+    v = run.readConfigFileToVariables(cfg)
+    assert v["resolution"] == 100000 and v["psig"] == 0.01 and v["modularity"] == 0.0
+    assert v["binGroupFile"] == str(tmp_path / "o") + "/binGroups.txt"          # prefixed at parse time (RUN:95-96)
+    assert v["avgClusterPlot"] == str(tmp_path / "p") + "/avgCluster.png"
+    assert v["hyperGeom"] is True and v["hmm"] is False and v["nScaffolds"] == 6
+    assert run.ensureAllVariablesAreSet(v) is False
+    # an empty value leaves the key unset -> refuse to run, also for part3/4 keys (RUN:221-239)
+    text = open(cfg).read().replace("validPairFile = /dev/null", "validPairFile = ")
+    (tmp_path / "c2.txt").write_text(text)
+    assert run.ensureAllVariablesAreSet(run.readConfigFileToVariables(str(tmp_path / "c2.txt"))) is True
+    # both strategies True -> refuse (RUN:230,241); bad numbers keep defaults; values keep leading blanks
+    text = open(cfg).read().replace("hmm = False", "hmm = true").replace("minSize = 5", "minSize = five") \
+        .replace("chromosomePlotSuffix = synthetic", "chromosomePlotSuffix =  500 Kb")
+    (tmp_path / "c3.txt").write_text(text + "\nthis line has no separator\n")
+    v3 = run.readConfigFileToVariables(str(tmp_path / "c3.txt"))
+    assert v3["hmm"] is True and v3["minSize"] == 5 and v3["chromosomePlotSuffix"] == " 500 Kb"
+    assert run.ensureAllVariablesAreSet(v3) is True
+
+
+def test_loaders_match_oracle(tmp_path):
+    from hic_genome_assembler_amd import hostio
+    paths = gc.write_case_files("n300_edges", str(tmp_path))
+    bins = hostio.initiateLoci(paths["hicProBedFile"], paths["hicProBiasFile"])
+    bins_o = orc.initiate_loci(paths["hicProBedFile"], paths["hicProBiasFile"])
+    assert [(b.ID, b.chrom, b.start, b.stop, b.bias) for b in bins] == \
+        [(b.ID, b.chrom, b.start, b.stop, b.bias) for b in bins_o]
+    assert len(bins) == 298                                      # two "nan" bias lines dropped (S2C:57)
+    m = hostio.read_contact_matrix(paths["hicProMatrixFile"], bins)
+    assert np.array_equal(m, orc.build_adjacency(paths["hicProMatrixFile"], bins_o))
+    # duplicates: the later line wins, unknown IDs are skipped (S2C:84-89)
+    dup = tmp_path / "dup.matrix"
+    dup.write_text("1\t2\t5.0\n2\t1\t7.5\n1\t999999\t3.0\n3\t3\t1.25\n1\t2\t9.0\n2\t3\t0.1\n")
+    some = bins[:3]
+    m2 = hostio.read_contact_matrix(str(dup), some)
+    assert np.array_equal(m2, orc.build_adjacency(str(dup), some))
+    subset = {b.ID: '' for b in bins[10:20]}
+    sub = hostio.initiateLoci(paths["hicProBedFile"], paths["hicProBiasFile"], binID_dict=subset)
+    assert [b.ID for b in sub] == [b.ID for b in bins[10:20]]
+
+
+def test_part1_rejects_unimplemented_strategies(tmp_path):
+    from hic_genome_assembler_amd import scaffoldToChromosomes as p1
+    args = ["x"] * 10
+    with pytest.raises(NotImplementedError):
+        p1.runPipeline(*args, False, True, 5, 0.0, 20, .05, 5, .2, 100000)
+    with pytest.raises(NotImplementedError):
+        p1.runPipeline(*args, True, False, 5, 0.05, 20, .05, 5, .2, 100000)
