@@ -45,6 +45,7 @@ SIGNATURES = {
     "hicmi_p2_select": (ctypes.c_int, [_vp, _vp, c_i64]),
     "hicmi_p2_total": (ctypes.c_int, [_vp, ctypes.POINTER(c_dbl)]),
     "hicmi_p2_score": (ctypes.c_int, [_vp, _vp, c_i64, c_i64, c_dbl, _vp]),
+    "hicmi_p2_score_exact": (ctypes.c_int, [_vp, _vp, c_i64, c_i64, c_dbl, _vp]),
     "hicmi_timing_reset": (ctypes.c_int, [_vp]),
     "hicmi_timing_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "hicmi_timing_get": (ctypes.c_int, [_vp, ctypes.c_char_p, c_i64, _vp, _vp, _vp, c_i64, ctypes.POINTER(c_i64)]),
@@ -199,6 +200,16 @@ class Context:
         out = np.empty(perms.shape[0], np.float64)
         if perms.shape[0]:
             _check(self._lib.hicmi_p2_score(self._h, _ptr(perms), perms.shape[0], perms.shape[1], float(total), _ptr(out)))
+        return out
+
+    def p2_score_exact(self, perms, total: float):
+        perms = np.ascontiguousarray(perms, dtype=np.int32)
+        if perms.ndim != 2:
+            raise ValueError("perms must be (n_cand, n_used)")
+        out = np.empty(perms.shape[0], np.float64)
+        if perms.shape[0]:
+            _check(self._lib.hicmi_p2_score_exact(self._h, _ptr(perms), perms.shape[0], perms.shape[1], float(total),
+                                                  _ptr(out)))
         return out
 
     # ---- misc

@@ -37,9 +37,10 @@ static int fail(int code, const char* fmt, ...)
     } while (0)
 
 enum Family { F_ROW_SUMS, F_BUILD_W, F_NNCHAIN, F_SORT, F_RANK_INVERT, F_CUT_COUNT, F_HYPER_FLAGS, F_P2_SELECT,
-              F_P2_TOTAL, F_P2_SCORE, F_COUNT };
+              F_P2_TOTAL, F_P2_SCORE, F_P2_EXACT, F_COUNT };
 static const char* kFamilyNames[F_COUNT] = {"row_sums", "build_w", "nnchain", "sort_rows", "rank_invert",
-                                            "cut_count", "hyper_flags", "p2_select", "p2_total", "p2_score"};
+                                            "cut_count", "hyper_flags", "p2_select", "p2_total", "p2_score",
+                                            "p2_score_exact"};
 
 struct TimedRegion { int fam; hipEvent_t a, b; };
 
@@ -73,6 +74,7 @@ struct hicmi_ctx {
     int32_t* d_perms = nullptr; int64_t perms_cap = 0;
     double* d_scores = nullptr; int64_t scores_cap = 0;
     double* d_partial = nullptr; int64_t partial_cap = 0;
+    double* d_T = nullptr; int64_t t_cap = 0;
     // timing
     bool timing = false;
     std::vector<TimedRegion> regions;
@@ -203,7 +205,7 @@ int hicmi_destroy(hicmi_ctx* c)
     free_dev(c->d_order); free_dev(c->dR); free_dev(c->dRank); free_dev(c->d_sort_scratch);
     free_dev(c->d_x); free_dev(c->d_sig); free_dev(c->d_tmp);
     free_dev(c->dM2); free_dev(c->d_sel); free_dev(c->d_H); free_dev(c->d_perms); free_dev(c->d_scores);
-    free_dev(c->d_partial);
+    free_dev(c->d_partial); free_dev(c->d_T);
     for (auto& r : c->regions) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
@@ -607,6 +609,34 @@ int hicmi_p2_score(hicmi_ctx* c, const int32_t* perms, int64_t n_cand, int64_t n
     {
         Timed t(c, F_P2_SCORE, 8.0 * (double)n_cand * 0.5 * (double)n_used * (double)(n_used - 1));
         launch_p2_score(c->dM2, c->ld2, c->d_perms, (int)n_cand, (int)n_used, c->d_H, 0.0, total, c->d_scores, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(scores_out, c->d_scores, sizeof(double) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HICMI_OK;
+}
+
+int hicmi_p2_score_exact(hicmi_ctx* c, const int32_t* perms, int64_t n_cand, int64_t n_used, double total,
+                         double* scores_out)
+{
+    if (!c || !perms || !scores_out || n_cand < 0 || n_used < 1) return fail(HICMI_EINVAL, "bad arguments");
+    if (c->n2 < 1) return fail(HICMI_EINVAL, "hicmi_p2_select has not run");
+    if (n_used > c->n2) return fail(HICMI_EINVAL, "n_used exceeds the selection");
+    if (n_cand == 0) return HICMI_OK;
+    if (n_used * (int64_t)sizeof(int32_t) > 160 * 1024) return fail(HICMI_EUNSUPPORTED, "candidate longer than 40960 bins");
+    for (int64_t i = 0; i < n_cand * n_used; i++)
+        if (perms[i] < 0 || perms[i] >= c->n2) return fail(HICMI_EINVAL, "candidate index out of range");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure(c->d_perms, c->perms_cap, n_cand * n_used);
+    if (rc) return rc;
+    rc = ensure(c->d_scores, c->scores_cap, n_cand);
+    if (rc) return rc;
+    rc = ensure(c->d_T, c->t_cap, n_cand * n_used);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->d_perms, perms, sizeof(int32_t) * (size_t)(n_cand * n_used), hipMemcpyHostToDevice, c->stream));
+    {
+        Timed t(c, F_P2_EXACT, 8.0 * (double)n_cand * 0.5 * (double)n_used * (double)(n_used - 1));
+        launch_p2_score_exact(c->dM2, c->ld2, c->d_perms, (int)n_cand, (int)n_used, total, c->d_T, c->d_scores, c->stream);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(scores_out, c->d_scores, sizeof(double) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));

@@ -29,7 +29,9 @@ void launch_similarity_row(const double* C, int64_t ldc, const int32_t* order, c
 
 // k_part2.hip
 void launch_p2_select(const double* C, int64_t ldc, const int32_t* sel, int n, double* M2, int64_t ld2, hipStream_t s);
-void launch_p2_total(const double* M2, int64_t ld2, int n, double* partial, double* total, hipStream_t s);
+void launch_p2_total(const double* M2, int64_t ld2, int n, double* T, double* total, hipStream_t s);
+void launch_p2_score_exact(const double* M2, int64_t ld2, const int32_t* perms, int n_cand, int n_used, double total,
+                           double* T, double* scores, hipStream_t s);
 void launch_p2_score(const double* M2, int64_t ld2, const int32_t* perms, int n_cand, int n_used, const double* H,
                      double inv_total_unused, double total, double* scores, hipStream_t s);
 

@@ -49,11 +49,38 @@ class SubMatrix:
         return self._total
 
     def scores(self, perms) -> np.ndarray:
-        """costFunction_numba (OG:184-191) of every row of ``perms`` (positions into this selection)."""
+        """costFunction_numba (OG:184-191) of every row of ``perms`` (positions into this selection),
+        closed form in fp64 (k_p2_score)."""
         perms = np.ascontiguousarray(perms, dtype=np.int32)
         if perms.shape[1] < 2:
             return np.zeros(perms.shape[0])             # range(1, 1) is empty: cost 0.0
         return self.ctx.p2_score(perms, self.total())
+
+    def first_strict_max(self, perms, floor):
+        """The reference's ``if cost > bestCost`` scan over the candidates in enumeration order
+        (OG:349,359,464,535), starting from ``bestCost = floor``: returns (index, cost) of the
+        winner or (-1, floor).  Those comparisons are decided at the last bit (the same arrangement
+        under two differently rounded totals differs by an ulp), so every candidate whose fast
+        score is within 1e-9 of the step's best is re-scored in the reference's exact operation
+        order (k_p2_diag_sums / hicmi_p2_score_exact) and the decision uses those values."""
+        perms = np.ascontiguousarray(perms, dtype=np.int32)
+        fast = self.scores(perms)
+        ok = np.isfinite(fast)
+        if not ok.any():
+            return -1, floor
+        top = max(float(fast[ok].max()), float(floor))
+        near = np.flatnonzero(ok & (fast >= top - abs(top) * 1e-9))
+        if len(near) == 0:
+            return -1, floor
+        if perms.shape[1] < 2:
+            exact = np.zeros(len(near))
+        else:
+            exact = self.ctx.p2_score_exact(perms[near], self.total())
+        pick, best = -1, floor
+        for c, v in zip(near, exact):
+            if v > best:
+                pick, best = int(c), float(v)
+        return pick, best
 
 
 def buildAdjacencyMatrix(matrixFile, binList, binID_dict=False, device=0, ctx=None):
@@ -254,11 +281,7 @@ def bruteForceBestScore(sObjList, scaffDict, matrix: SubMatrix, orderDict):
         onames = [names[i] for i in o]
         for r in orients:
             rows.append(np.concatenate([fwd[nm] if sg == "+" else rev[nm] for nm, sg in zip(onames, r)]))
-    scores = matrix.scores(np.stack(rows))
-    best, best_c = -1, 0.
-    for c, v in enumerate(scores):                      # first strict maximum above 0. (OG:464)
-        if v > best_c:
-            best, best_c = c, float(v)
+    best, best_c = matrix.first_strict_max(np.stack(rows), 0.)     # first strict maximum above 0. (OG:464)
     # the enumeration leaves every scaffold in the last candidate's orientation (OG:459)
     reorderScaffList([names[i] for i in orders[-1]], orients[-1], scaffDict)
     if best < 0:
@@ -282,11 +305,8 @@ def checkAllScores(adjMat: SubMatrix, orderDict, orderedScaffs, scaffToCheck):
             tags.append((i, o))
             if _half == 0:
                 cur, o = cur[::-1], flip[o]
-    scores = adjMat.scores(np.stack(rows))
-    bestCost, bestGap, bestOrient = 0., 0, "+"
-    for (i, orient), v in zip(tags, scores):
-        if v > bestCost:
-            bestCost, bestGap, bestOrient = float(v), i, orient
+    pick, bestCost = adjMat.first_strict_max(np.stack(rows), 0.)
+    bestGap, bestOrient = tags[pick] if pick >= 0 else (0, "+")
     if gaps % 2 == 1:                                   # one flip per gap (OG:356)
         scaffToCheck.flipOrientation()
     if scaffToCheck.orientation != bestOrient:
@@ -333,11 +353,7 @@ def scanOrdering(orderedScaffolds, scaffoldDict, orderDict, matrix: GenomeMatrix
             for o in orders:
                 for r in orients:
                     rows.append(np.concatenate([head] + [fwd[j] if sg == "+" else rev[j] for j, sg in zip(o, r)] + [tail]))
-            scores = adjMat.scores(np.stack(rows))
-            pick = -1
-            for c, v in enumerate(scores):              # running strict '>' against the global best (OG:535)
-                if v > bestCost:
-                    bestCost, pick = float(v), c
+            pick, bestCost = adjMat.first_strict_max(np.stack(rows), bestCost)   # strict '>' vs the global best (OG:535)
             if pick >= 0:
                 improved = True
                 o, r = orders[pick // len(orients)], orients[pick % len(orients)]
@@ -437,14 +453,24 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, chromosomeGroup
     binList = initiateLoci(hicProBedFile, hicProBiasFile, binID_dict=binDict)
     adjMat = buildAdjacencyMatrix(hicProMatrixFile, binList, device=device)
     try:
-        chromosomeList = readChromsFromFile(chromosomeGroupFile)
-        orderedChromosomes = orderGenome(adjMat, chromosomeList, binList, resolution, nScaffolds=nScaffolds,
-                                         scanScaffolds=scanScaffolds, plotChrom=True, showPlot=False,
-                                         savePlotDir=savePlotsDirectory, plotTitleSuffix=chromosomePlotSuffix)
+        runResident(adjMat, binList, chromosomeGroupFile, chromosomeOrderFile, plotOrderFile, nScaffolds,
+                    scanScaffolds, resolution)
     finally:
         adjMat.ctx.close()
     print("- plotting is not part of the MI355X hot path: " + str(fullGenomePlot) + " not written")
-    writeScaffoldOrderingsToFile(orderedChromosomes, chromosomeOrderFile)
-    writeBinIDsOrderingToFile([s for group in orderedChromosomes for s in group], plotOrderFile)
     print("Total run-time  for Part2 = " + str(time.time() - t0))
     print("- Part 2 (chromosome ordering) completed successfully")
+
+
+def runResident(adjMat: GenomeMatrix, binList, chromosomeGroupFile, chromosomeOrderFile, plotOrderFile,
+                nScaffolds, scanScaffolds, resolution):
+    """OG:691-709 on contacts that are already resident in HBM (what bench.py times).  ``binList``
+    gives the bin of every row of the device matrix; bins that Part 1 did not assign to a group are
+    simply never selected, which is what the reference's re-load restricted to grouped bins
+    (OG:688-690) amounts to."""
+    chromosomeList = readChromsFromFile(chromosomeGroupFile)
+    orderedChromosomes = orderGenome(adjMat, chromosomeList, binList, resolution, nScaffolds=nScaffolds,
+                                     scanScaffolds=scanScaffolds, plotChrom=True, showPlot=False)
+    writeScaffoldOrderingsToFile(orderedChromosomes, chromosomeOrderFile)
+    writeBinIDsOrderingToFile([s for group in orderedChromosomes for s in group], plotOrderFile)
+    return orderedChromosomes

@@ -398,27 +398,39 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, hicProScaffSize
     if modularity is not False and modularity > 0.0:
         raise NotImplementedError("modularity > 0 (Louvain tail, unseeded random in the reference, S2C:253) "
                                   "is not implemented: set `modularity = 0`")
-    t0 = time.time()
     binList = initiateLoci(hicProBedFile, hicProBiasFile)
     adjMat = buildAdjacencyMatrix(hicProMatrixFile, binList, device=device)
     try:
-        adjMat, binList = removeRows(adjMat, binList, zeroRows=True, biasVals=False)
-        adjMat = convertMatrix(adjMat, binList, distance=True, similarity=False)
-        dendroLabels = [b.chrom + '_' + str(b.ID) for b in binList]
-        dendrogram = averageClusterNodes(adjMat, dendroLabels, noPlot=True)
-        dendrogramLeafOrder_toFile(dendrogram, dendrogramOrderFile)
-        dendoLeaves = readDengrogramLeavesFromFile(dendrogramOrderFile)
-        adjMat, binList = reorderMatrix(adjMat, binList, dendoLeaves['leaves'])
-        print("- plotting is not part of the MI355X hot path: " + str(avgClusterPlot) + " not written")
-        print("Total run-time to cluster = " + str(time.time() - t0))
-        t0 = time.time()
-        adjMat = convertMatrix(adjMat, binList, distance=False, similarity=True)
-        argsorted_adjMat = rankOrderMatrix(adjMat)
-        initial_cut_inds = pre_process_all_matrix_breakpoints(argsorted_adjMat, min_size=minSize,
-                                                              min_frac=modularity, psig=psig)
-        cutIndices = filter_noisy_breakpoints(argsorted_adjMat, initial_cut_inds, psig=psig)
+        cutIndices = runResident(adjMat, binList, hicProScaffSizeFile, dendrogramOrderFile, binGroupFile,
+                                 assessmentFile, chromosomeGroupFile, minSize, modularity, psig)
     finally:
         adjMat.ctx.close()
+    print("Total run-time of Part1 = " + str(time.time() - t_all))
+    print("CutIndices = " + str(cutIndices))
+    print("- Part 1 (grouping bins to groups) completed successfully")
+
+
+def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOrderFile, binGroupFile,
+                assessmentFile, chromosomeGroupFile, minSize, modularity, psig):
+    """S2C:1117-1167 on a contact map that is already resident in HBM (what bench.py times): every
+    stage after the text loaders, including the small intermediate files the reference round-trips
+    through.  Returns the filtered cut indices; ``binList`` is left in .bed order for the caller."""
+    t0 = time.time()
+    adjMat, binList = removeRows(adjMat, binList, zeroRows=True, biasVals=False)
+    adjMat.kept_bins = list(binList)                  # rows of the device matrix, in .bed order
+    adjMat = convertMatrix(adjMat, binList, distance=True, similarity=False)
+    dendroLabels = [b.chrom + '_' + str(b.ID) for b in binList]
+    dendrogram = averageClusterNodes(adjMat, dendroLabels, noPlot=True)
+    dendrogramLeafOrder_toFile(dendrogram, dendrogramOrderFile)
+    dendoLeaves = readDengrogramLeavesFromFile(dendrogramOrderFile)
+    adjMat, binList = reorderMatrix(adjMat, binList, dendoLeaves['leaves'])
+    print("Total run-time to cluster = " + str(time.time() - t0))
+    t0 = time.time()
+    adjMat = convertMatrix(adjMat, binList, distance=False, similarity=True)
+    argsorted_adjMat = rankOrderMatrix(adjMat)
+    initial_cut_inds = pre_process_all_matrix_breakpoints(argsorted_adjMat, min_size=minSize,
+                                                          min_frac=modularity, psig=psig)
+    cutIndices = filter_noisy_breakpoints(argsorted_adjMat, initial_cut_inds, psig=psig)
     writeBinGroupingsToFile(cutIndices, binList, binGroupFile)
     print("Total run-time to identify chromosome boundaries = " + str(time.time() - t0))
     t0 = time.time()
@@ -427,6 +439,4 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, hicProScaffSize
     chrGroups = assessChromosomeClustering(binGroups, assessmentFile)
     writeChromosomeGroupingsToFile(chrGroups, fastaSizeDict, chromosomeGroupFile)
     print("Total run-time to assign scaffolds to chromosomes = " + str(time.time() - t0))
-    print("Total run-time of Part1 = " + str(time.time() - t_all))
-    print("CutIndices = " + str(cutIndices))
-    print("- Part 1 (grouping bins to groups) completed successfully")
+    return cutIndices

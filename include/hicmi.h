@@ -111,7 +111,8 @@ int hicmi_get_raw_merges(hicmi_ctx *ctx, double *Zraw_out);
  * giveNewAdjMat (OG:296-308): select the sub-matrix of the context's contact matrix for the bins
  * sel[0..n) (indices into the contact matrix); later candidates index into this selection. */
 int hicmi_p2_select(hicmi_ctx *ctx, const int32_t *sel, int64_t n);
-/* total = sum of all entries above the diagonal of the selected sub-matrix (OG:343,448,506). */
+/* total = sum of all entries above the diagonal of the selected sub-matrix, with the reference's
+ * own rounding: Python sum over offsets 1..n-1 of numpy.trace(adjMat, offset) (OG:343,448,506). */
 int hicmi_p2_total(hicmi_ctx *ctx, double *total_out);
 /* costFunction_numba (OG:184-191) of n_cand candidate orders at once.  perms: n_cand x n_used
  * int32 positions into the current selection (the reference's nOrder lists, OG:347,357,460,532);
@@ -119,6 +120,13 @@ int hicmi_p2_total(hicmi_ctx *ctx, double *total_out);
  * scores. */
 int hicmi_p2_score(hicmi_ctx *ctx, const int32_t *perms, int64_t n_cand, int64_t n_used, double total,
                    double *scores_out);
+/* The same objective in the reference's exact operation order (numpy.trace pairwise sums per
+ * offset, then the sequential cum/total/i recurrence, OG:185-191): bit-identical to the reference's
+ * NumPy path.  The search compares scores that can differ by one ulp (OG:349,359,464,535), so the
+ * candidates within 1e-9 of a step's best hicmi_p2_score are re-scored with this entry point and
+ * the decision is taken on these values. */
+int hicmi_p2_score_exact(hicmi_ctx *ctx, const int32_t *perms, int64_t n_cand, int64_t n_used, double total,
+                         double *scores_out);
 
 /* ---- timing ----------------------------------------------------------------------------------
  * Accumulated device time (HIP events on the context stream) per kernel family since the last

@@ -460,12 +460,17 @@ def write_chromosome_groupings(chrom_list, size_dict, path):
 
 
 def run_part1(bed, bias, matrix, sizes, dendro_file, bin_group_file, assessment_file, chrom_group_file,
-              min_size=5, modularity=0.0, psig=.05, trace=None):
-    """S2C:1104-1174 on the hyperGeom=True, hmm=False, modularity=0 path (plots omitted)."""
+              min_size=5, modularity=0.0, psig=.05, trace=None, preloaded=None):
+    """S2C:1104-1174 on the hyperGeom=True, hmm=False, modularity=0 path (plots omitted).
+    ``preloaded=(matrix, bins)`` skips the text loaders (bench.py's cpu_baseline leg times the same
+    resident-matrix path as the GPU)."""
     if modularity not in (0, 0.0, False):
         raise NotImplementedError("oracle covers modularity = 0 only (Louvain tail is unseeded random, S2C:253)")
-    bins = initiate_loci(bed, bias)
-    mat = build_adjacency(matrix, bins)
+    if preloaded is not None:
+        mat, bins = np.array(preloaded[0], dtype=np.float64), list(preloaded[1])
+    else:
+        bins = initiate_loci(bed, bias)
+        mat = build_adjacency(matrix, bins)
     mat, bins = remove_zero_rows(mat, bins)
     dist = to_distance(mat)
     labels = [b.chrom + "_" + str(b.ID) for b in bins]
@@ -725,11 +730,15 @@ def write_bin_id_ordering(scaffolds, path):
 
 
 def run_part2(bed, bias, matrix, chrom_group_file, chrom_order_file, plot_order_file,
-              n_scaffolds=6, scan_scaffolds=5, trace=None):
-    """OG:679-712 (plots omitted)."""
+              n_scaffolds=6, scan_scaffolds=5, trace=None, preloaded=None):
+    """OG:679-712 (plots omitted).  ``preloaded=(matrix, bins)`` skips the text loaders; bins that
+    are not in the group file are never selected, as in the reference's restricted re-load."""
     ids = read_groupings_to_valid_bins(chrom_group_file)
-    bins = initiate_loci(bed, bias, bin_ids=ids)
-    mat = build_adjacency(matrix, bins)
+    if preloaded is not None:
+        mat, bins = np.ascontiguousarray(preloaded[0], dtype=np.float64), list(preloaded[1])
+    else:
+        bins = initiate_loci(bed, bias, bin_ids=ids)
+        mat = build_adjacency(matrix, bins)
     chroms = read_chroms(chrom_group_file)
     orc = Part2Oracle(mat, bins)
     out, marks, bests = [], [], []

@@ -1,0 +1,81 @@
+"""A stand-in for hic_genome_assembler_amd._lib.Context that answers every C-ABI call with the CPU
+oracle.  TEST INFRASTRUCTURE: lets the CPU suite exercise the product's HOST control flow
+(cut-candidate loops, scaffold search, file writers) without a GPU.  It is never importable from
+the package and the product has no path that reaches it."""
+import numpy as np
+
+import hic_oracle as orc
+
+
+class OracleContext:
+    def __init__(self, device=0):
+        self.n = 0
+        self.mat = None
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        pass
+
+    def set_contacts(self, mat):
+        self.mat = np.ascontiguousarray(mat, dtype=np.float64)
+        self.n = len(self.mat)
+
+    def row_sums(self):
+        return orc.np_row_sums(self.mat), orc.seq_row_sums(self.mat)
+
+    def compact(self, keep):
+        keep = np.asarray(keep, dtype=np.int64)
+        self.set_contacts(self.mat[np.ix_(keep, keep)])
+
+    def upgma(self, want_linkage=True):
+        leaves, z = orc.average_cluster_leaves(orc.to_distance(self.mat))
+        return leaves, z
+
+    def rank_matrix(self, order):
+        order = np.asarray(order, dtype=np.int64)
+        dist = orc.to_distance(self.mat)[:, order][order]
+        rs = orc.seq_row_sums(self.mat)[order]
+        sim = rs[:, None] * (1.0 - (dist - 1.0))
+        self.R = orc.rank_order(sim)
+
+    def rank_rows(self, row0=0, nrows=None, inverse=False):
+        assert not inverse
+        nrows = self.n - row0 if nrows is None else nrows
+        return self.R[row0:row0 + nrows].astype(np.uint16)
+
+    def cut_scan(self, start, M, psig, want_x=False):
+        x = orc.first_pass_counts(self.R, start)[start:]
+        L = np.arange(1, self.n - start)
+        p = orc.hyper_geom(x[1:], M, L, L)
+        sig = np.concatenate(([0], np.where(p >= psig, 0, 1))).astype(np.uint8)
+        return (sig, x.astype(np.int32)) if want_x else sig
+
+    def filter_scan(self, start, c, n_rows, M, psig, want_x=False):
+        sub = self.R[start:start + n_rows, :c - start]
+        x = np.count_nonzero((sub >= start) & (sub <= c), axis=1)
+        p = orc.hyper_geom(x, M, c - start, c - start)
+        sig = np.where(p < psig, 1, 0).astype(np.uint8)
+        return (sig, x.astype(np.int32)) if want_x else sig
+
+    def p2_select(self, sel):
+        sel = np.asarray(sel, dtype=np.int64)
+        self.sub = np.ascontiguousarray(self.mat[np.ix_(sel, sel)])
+
+    def p2_total(self):
+        n = len(self.sub)
+        ident = np.arange(n, dtype=np.int32)
+        return orc.lib().hio_total_upper(orc._dp(self.sub), n, orc._ip(ident), n)
+
+    def p2_score(self, perms, total):
+        perms = np.ascontiguousarray(perms, dtype=np.int32)
+        out = np.zeros(len(perms))
+        orc.lib().hio_cost_literal_batch(orc._dp(self.sub), self.sub.shape[1], orc._ip(perms), perms.shape[0],
+                                         perms.shape[1], float(total), orc._dp(out))
+        return out
+
+    p2_score_exact = p2_score

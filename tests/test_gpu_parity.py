@@ -228,6 +228,31 @@ def test_p2_scores_match_literal_cost(hic, orc):
     assert short.shape == (64,)
 
 
+@pytest.mark.parametrize("n_used", [2, 7, 8, 9, 127, 128, 129, 200, 1000])
+def test_p2_literal_scores_bit_exact(hic, orc, n_used):
+    """hicmi_p2_total / hicmi_p2_score_exact reproduce the reference's NumPy arithmetic bit for bit
+    (numpy.trace pairwise sums per offset, sequential cum/total/i), which is what decides the
+    ulp-level `cost > bestCost` comparisons of orderGenome.py:349,359,464,535."""
+    rng = np.random.default_rng(n_used)
+    n = n_used + 13
+    m = rng.random((n, n)) * 7.0; m = m + m.T
+    sel = rng.permutation(n)[:n_used].astype(np.int32)
+    perms = np.stack([rng.permutation(n_used) for _ in range(9)]).astype(np.int32)
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(m)
+        ctx.p2_select(sel)
+        total = ctx.p2_total()
+        exact = ctx.p2_score_exact(perms, total)
+        fast = ctx.p2_score(perms, total)
+    L = orc.lib()
+    sub = np.ascontiguousarray(m[np.ix_(sel, sel)])
+    ident = np.arange(n_used, dtype=np.int32)
+    assert total == L.hio_total_upper(orc._dp(sub), n_used, orc._ip(ident), n_used)
+    for k in range(len(perms)):
+        assert exact[k] == L.hio_cost_literal(orc._dp(sub), n_used, orc._ip(perms[k]), n_used, total)
+    assert np.allclose(fast, exact, rtol=1e-11, atol=0)
+
+
 # --------------------------------------------------------------------------------- end to end
 def _run_product(name, tmp_path, record=None):
     from hic_genome_assembler_amd import scaffoldToChromosomes as p1, orderGenome as p2
