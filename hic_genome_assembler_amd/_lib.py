@@ -64,6 +64,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise HicmiError("libhicmi.so is not built (%s): run `make -C %s` - this package has no CPU fallback"
                          % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    try:
+        # PyTorch-ROCm bundles its own libamdhip64; if a second copy (the /opt/rocm one libhicmi links
+        # against) initialises first, torch later reports "no ROCm-capable device".  Loading torch
+        # first makes both share one HIP runtime.  torch is plumbing only (device buffers, RCCL).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
