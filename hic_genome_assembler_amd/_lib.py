@@ -46,6 +46,13 @@ SIGNATURES = {
     "hicmi_p2_total": (ctypes.c_int, [_vp, ctypes.POINTER(c_dbl)]),
     "hicmi_p2_score": (ctypes.c_int, [_vp, _vp, c_i64, c_i64, c_dbl, _vp]),
     "hicmi_p2_score_exact": (ctypes.c_int, [_vp, _vp, c_i64, c_i64, c_dbl, _vp]),
+    "hicmi_p2_layout": (ctypes.c_int, [_vp, _vp, _vp, c_i64]),
+    "hicmi_p2_set_arrangement": (ctypes.c_int, [_vp, _vp, _vp, c_i64]),
+    "hicmi_p2_arrangement_total": (ctypes.c_int, [_vp, ctypes.POINTER(c_dbl)]),
+    "hicmi_p2_arrangement_score": (ctypes.c_int, [_vp, c_dbl, ctypes.POINTER(c_dbl)]),
+    "hicmi_p2_score_insertions": (ctypes.c_int, [_vp, ctypes.c_int32, c_dbl, _vp]),
+    "hicmi_p2_window_tables": (ctypes.c_int, [_vp, c_i64, _vp, c_i64, _vp, c_i64]),
+    "hicmi_p2_score_window": (ctypes.c_int, [_vp, c_i64, c_i64, _vp]),
     "hicmi_timing_reset": (ctypes.c_int, [_vp]),
     "hicmi_timing_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "hicmi_timing_get": (ctypes.c_int, [_vp, ctypes.c_char_p, c_i64, _vp, _vp, _vp, c_i64, ctypes.POINTER(c_i64)]),
@@ -217,6 +224,44 @@ class Context:
         if perms.shape[0]:
             _check(self._lib.hicmi_p2_score_exact(self._h, _ptr(perms), perms.shape[0], perms.shape[1], float(total),
                                                   _ptr(out)))
+        return out
+
+    # ---- Part 2 search with device-side enumeration
+    def p2_layout(self, scaf_start, scaf_len):
+        a = np.ascontiguousarray(scaf_start, dtype=np.int32)
+        b = np.ascontiguousarray(scaf_len, dtype=np.int32)
+        _check(self._lib.hicmi_p2_layout(self._h, _ptr(a), _ptr(b), len(a)))
+
+    def p2_set_arrangement(self, ids, rev):
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        b = np.ascontiguousarray(rev, dtype=np.uint8)
+        _check(self._lib.hicmi_p2_set_arrangement(self._h, _ptr(a), _ptr(b), len(a)))
+        self._arr_len = len(a)
+
+    def p2_arrangement_total(self) -> float:
+        t = c_dbl()
+        _check(self._lib.hicmi_p2_arrangement_total(self._h, ctypes.byref(t)))
+        return t.value
+
+    def p2_arrangement_score(self, total: float) -> float:
+        t = c_dbl()
+        _check(self._lib.hicmi_p2_arrangement_score(self._h, float(total), ctypes.byref(t)))
+        return t.value
+
+    def p2_score_insertions(self, new_id: int, total: float):
+        out = np.empty(2 * (self._arr_len + 1), np.float64)
+        _check(self._lib.hicmi_p2_score_insertions(self._h, int(new_id), float(total), _ptr(out)))
+        return out
+
+    def p2_window_tables(self, orders, orients):
+        a = np.ascontiguousarray(orders, dtype=np.int8)
+        b = np.ascontiguousarray(orients, dtype=np.uint8)
+        _check(self._lib.hicmi_p2_window_tables(self._h, a.shape[1], _ptr(a), a.shape[0], _ptr(b), b.shape[0]))
+        self._n_window_cand = a.shape[0] * b.shape[0]
+
+    def p2_score_window(self, first: int, k: int):
+        out = np.empty(self._n_window_cand, np.float64)
+        _check(self._lib.hicmi_p2_score_window(self._h, int(first), int(k), _ptr(out)))
         return out
 
     # ---- misc

@@ -37,10 +37,10 @@ static int fail(int code, const char* fmt, ...)
     } while (0)
 
 enum Family { F_ROW_SUMS, F_BUILD_W, F_NNCHAIN, F_SORT, F_RANK_INVERT, F_CUT_COUNT, F_HYPER_FLAGS, F_P2_SELECT,
-              F_P2_TOTAL, F_P2_SCORE, F_P2_EXACT, F_COUNT };
+              F_P2_TOTAL, F_P2_SCORE, F_P2_EXACT, F_P2_INSERT, F_P2_WINDOW_G, F_P2_WINDOW_DELTA, F_COUNT };
 static const char* kFamilyNames[F_COUNT] = {"row_sums", "build_w", "nnchain", "sort_rows", "rank_invert",
                                             "cut_count", "hyper_flags", "p2_select", "p2_total", "p2_score",
-                                            "p2_score_exact"};
+                                            "p2_score_exact", "p2_score_insert", "p2_window_G", "p2_window_delta"};
 
 struct TimedRegion { int fam; hipEvent_t a, b; };
 
@@ -75,6 +75,17 @@ struct hicmi_ctx {
     double* d_scores = nullptr; int64_t scores_cap = 0;
     double* d_partial = nullptr; int64_t partial_cap = 0;
     double* d_T = nullptr; int64_t t_cap = 0;
+    // part 2 search state: layout (scaffold ranges of the selection), arrangement, window tables
+    int32_t *d_scaf_start = nullptr, *d_scaf_len = nullptr; int64_t scaf_cap = 0, n_scaf = 0;
+    std::vector<int32_t> h_scaf_start, h_scaf_len;
+    int32_t *d_arr_id = nullptr, *d_arr_pos = nullptr; uint8_t* d_arr_rev = nullptr; int64_t arr_cap = 0;
+    std::vector<int32_t> h_arr_id, h_arr_pos; std::vector<uint8_t> h_arr_rev;
+    int32_t* d_pos2sel = nullptr; int64_t pos_cap = 0; int64_t n_arr = 0;
+    int8_t* d_orders = nullptr; uint8_t* d_orients = nullptr; int64_t ord_cap = 0, ori_cap = 0;
+    int tab_k = 0; int64_t n_orders = 0, n_orients = 0;
+    double* d_G = nullptr; int64_t g_cap = 0;
+    double* d_delta = nullptr; int64_t delta_cap = 0;
+    int32_t *d_win_id = nullptr, *d_win_off = nullptr; uint8_t* d_win_rev = nullptr;
     // timing
     bool timing = false;
     std::vector<TimedRegion> regions;
@@ -206,6 +217,9 @@ int hicmi_destroy(hicmi_ctx* c)
     free_dev(c->d_x); free_dev(c->d_sig); free_dev(c->d_tmp);
     free_dev(c->dM2); free_dev(c->d_sel); free_dev(c->d_H); free_dev(c->d_perms); free_dev(c->d_scores);
     free_dev(c->d_partial); free_dev(c->d_T);
+    free_dev(c->d_scaf_start); free_dev(c->d_scaf_len); free_dev(c->d_arr_id); free_dev(c->d_arr_pos);
+    free_dev(c->d_arr_rev); free_dev(c->d_pos2sel); free_dev(c->d_orders); free_dev(c->d_orients);
+    free_dev(c->d_G); free_dev(c->d_delta); free_dev(c->d_win_id); free_dev(c->d_win_off); free_dev(c->d_win_rev);
     for (auto& r : c->regions) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
@@ -571,6 +585,7 @@ int hicmi_p2_select(hicmi_ctx* c, const int32_t* sel, int64_t n)
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     c->n2 = n; c->ld2 = ld2;
+    c->n_scaf = 0; c->n_arr = 0; c->h_arr_id.clear();
     return HICMI_OK;
 }
 
@@ -640,6 +655,192 @@ int hicmi_p2_score_exact(hicmi_ctx* c, const int32_t* perms, int64_t n_cand, int
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(scores_out, c->d_scores, sizeof(double) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HICMI_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Part 2 search with device-side candidate enumeration (k_part2_search.hip)
+int hicmi_p2_layout(hicmi_ctx* c, const int32_t* scaf_start, const int32_t* scaf_len, int64_t n_scaf)
+{
+    if (!c || !scaf_start || !scaf_len || n_scaf < 1) return fail(HICMI_EINVAL, "bad arguments");
+    if (c->n2 < 1) return fail(HICMI_EINVAL, "hicmi_p2_select has not run");
+    for (int64_t i = 0; i < n_scaf; i++)
+        if (scaf_len[i] < 1 || scaf_start[i] < 0 || (int64_t)scaf_start[i] + scaf_len[i] > c->n2)
+            return fail(HICMI_EINVAL, "scaffold %lld is not a range of the selection", (long long)i);
+    HIPCHK(hipSetDevice(c->device));
+    if (c->scaf_cap < n_scaf) {
+        free_dev(c->d_scaf_start); free_dev(c->d_scaf_len); c->d_scaf_start = c->d_scaf_len = nullptr; c->scaf_cap = 0;
+        HIPCHK(hipMalloc((void**)&c->d_scaf_start, sizeof(int32_t) * (size_t)n_scaf));
+        HIPCHK(hipMalloc((void**)&c->d_scaf_len, sizeof(int32_t) * (size_t)n_scaf));
+        c->scaf_cap = n_scaf;
+    }
+    c->h_scaf_start.assign(scaf_start, scaf_start + n_scaf);
+    c->h_scaf_len.assign(scaf_len, scaf_len + n_scaf);
+    c->n_scaf = n_scaf; c->n_arr = 0;
+    HIPCHK(hipMemcpyAsync(c->d_scaf_start, scaf_start, sizeof(int32_t) * (size_t)n_scaf, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_scaf_len, scaf_len, sizeof(int32_t) * (size_t)n_scaf, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HICMI_OK;
+}
+
+int hicmi_p2_set_arrangement(hicmi_ctx* c, const int32_t* ids, const uint8_t* rev, int64_t S)
+{
+    if (!c || !ids || !rev || S < 1) return fail(HICMI_EINVAL, "bad arguments");
+    if (c->n_scaf < 1) return fail(HICMI_EINVAL, "hicmi_p2_layout has not run");
+    std::vector<int32_t> pos((size_t)S + 1, 0);
+    std::vector<uint8_t> used((size_t)c->n_scaf, 0);
+    for (int64_t j = 0; j < S; j++) {
+        if (ids[j] < 0 || ids[j] >= c->n_scaf || used[(size_t)ids[j]]) return fail(HICMI_EINVAL, "arrangement must list distinct scaffolds of the layout");
+        used[(size_t)ids[j]] = 1;
+        pos[(size_t)j + 1] = pos[(size_t)j] + c->h_scaf_len[(size_t)ids[j]];
+    }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->arr_cap < S + 1) {
+        free_dev(c->d_arr_id); free_dev(c->d_arr_pos); free_dev(c->d_arr_rev);
+        c->d_arr_id = c->d_arr_pos = nullptr; c->d_arr_rev = nullptr; c->arr_cap = 0;
+        int64_t cap = std::max<int64_t>(S + 1, c->n_scaf + 1);
+        HIPCHK(hipMalloc((void**)&c->d_arr_id, sizeof(int32_t) * (size_t)cap));
+        HIPCHK(hipMalloc((void**)&c->d_arr_pos, sizeof(int32_t) * (size_t)cap));
+        HIPCHK(hipMalloc((void**)&c->d_arr_rev, (size_t)cap));
+        c->arr_cap = cap;
+    }
+    int rc = ensure(c->d_pos2sel, c->pos_cap, c->n2);
+    if (rc) return rc;
+    c->h_arr_id.assign(ids, ids + S); c->h_arr_rev.assign(rev, rev + S); c->h_arr_pos = pos;
+    c->n_arr = pos[(size_t)S];
+    HIPCHK(hipMemcpyAsync(c->d_arr_id, ids, sizeof(int32_t) * (size_t)S, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_arr_rev, rev, (size_t)S, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_arr_pos, pos.data(), sizeof(int32_t) * (size_t)(S + 1), hipMemcpyHostToDevice, c->stream));
+    launch_arr_materialize(c->d_arr_id, c->d_arr_rev, c->d_arr_pos, (int)S, c->d_scaf_start, c->d_scaf_len, (int)c->n_arr,
+                           c->d_pos2sel, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));       // the host vectors above are reused by the next call
+    return HICMI_OK;
+}
+
+int hicmi_p2_arrangement_total(hicmi_ctx* c, double* total_out)
+{
+    if (!c || !total_out) return fail(HICMI_EINVAL, "bad arguments");
+    if (c->n_arr < 1) return fail(HICMI_EINVAL, "hicmi_p2_set_arrangement has not run");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure(c->d_T, c->t_cap, c->n_arr + 1);
+    if (rc) return rc;
+    rc = ensure(c->d_scores, c->scores_cap, 1);
+    if (rc) return rc;
+    {
+        Timed t(c, F_P2_TOTAL, 4.0 * (double)c->n_arr * (double)c->n_arr);
+        launch_p2_total_perm(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, c->d_T, c->d_scores, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(total_out, c->d_scores, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HICMI_OK;
+}
+
+int hicmi_p2_arrangement_score(hicmi_ctx* c, double total, double* score_out)
+{
+    if (!c || !score_out) return fail(HICMI_EINVAL, "bad arguments");
+    if (c->n_arr < 1) return fail(HICMI_EINVAL, "hicmi_p2_set_arrangement has not run");
+    if (c->n_arr < 2) { *score_out = 0.0; return HICMI_OK; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure(c->d_scores, c->scores_cap, 1);
+    if (rc) return rc;
+    {
+        Timed t(c, F_P2_SCORE, 4.0 * (double)c->n_arr * (double)(c->n_arr - 1));
+        launch_p2_score_arr(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, c->d_H, total, c->d_scores, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(score_out, c->d_scores, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HICMI_OK;
+}
+
+int hicmi_p2_score_insertions(hicmi_ctx* c, int32_t new_id, double total, double* scores_out)
+{
+    if (!c || !scores_out) return fail(HICMI_EINVAL, "bad arguments");
+    if (c->n_scaf < 1) return fail(HICMI_EINVAL, "hicmi_p2_layout has not run");
+    if (new_id < 0 || new_id >= c->n_scaf) return fail(HICMI_EINVAL, "new scaffold out of range");
+    const int64_t S = (int64_t)c->h_arr_id.size();
+    if (c->n_arr < 1 || S < 1) return fail(HICMI_EINVAL, "hicmi_p2_set_arrangement has not run");
+    for (int64_t j = 0; j < S; j++) if (c->h_arr_id[(size_t)j] == new_id) return fail(HICMI_EINVAL, "scaffold is already in the arrangement");
+    const int new_len = c->h_scaf_len[(size_t)new_id];
+    if ((c->n_arr + new_len) * (int64_t)sizeof(int32_t) > 160 * 1024) return fail(HICMI_EUNSUPPORTED, "candidate longer than 40960 bins");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure(c->d_scores, c->scores_cap, 2 * (S + 1));
+    if (rc) return rc;
+    {
+        const double nn = (double)(c->n_arr + new_len);
+        Timed t(c, F_P2_INSERT, 8.0 * 2.0 * (double)(S + 1) * 0.5 * nn * (nn - 1.0));
+        launch_p2_score_insert(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, c->d_arr_pos, (int)S,
+                               c->h_scaf_start[(size_t)new_id], new_len, c->d_H, total, c->d_scores, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(scores_out, c->d_scores, sizeof(double) * (size_t)(2 * (S + 1)), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HICMI_OK;
+}
+
+int hicmi_p2_window_tables(hicmi_ctx* c, int64_t k, const int8_t* orders, int64_t n_orders, const uint8_t* orients,
+                           int64_t n_orients)
+{
+    if (!c || !orders || !orients || k < 1 || k > 8 || n_orders < 1 || n_orients < 1) return fail(HICMI_EINVAL, "bad arguments");
+    for (int64_t i = 0; i < n_orders * k; i++) if (orders[i] < 0 || orders[i] >= k) return fail(HICMI_EINVAL, "order table entry out of range");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure(c->d_orders, c->ord_cap, n_orders * k);
+    if (rc) return rc;
+    rc = ensure(c->d_orients, c->ori_cap, n_orients * k);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->d_orders, orders, (size_t)(n_orders * k), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_orients, orients, (size_t)(n_orients * k), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->tab_k = (int)k; c->n_orders = n_orders; c->n_orients = n_orients;
+    return HICMI_OK;
+}
+
+int hicmi_p2_score_window(hicmi_ctx* c, int64_t first, int64_t k, double* delta_out)
+{
+    if (!c || !delta_out) return fail(HICMI_EINVAL, "bad arguments");
+    const int64_t S = (int64_t)c->h_arr_id.size();
+    if (c->n_arr < 1 || S < 1) return fail(HICMI_EINVAL, "hicmi_p2_set_arrangement has not run");
+    if (k != c->tab_k) return fail(HICMI_EINVAL, "hicmi_p2_window_tables has not been called for k = %lld", (long long)k);
+    if (first < 0 || first + k > S) return fail(HICMI_EINVAL, "window out of range");
+    HIPCHK(hipSetDevice(c->device));
+    const int p0 = c->h_arr_pos[(size_t)first], p1 = c->h_arr_pos[(size_t)(first + k)], m = p1 - p0;
+    const int64_t n_cand = c->n_orders * c->n_orients;
+    int rc = ensure(c->d_G, c->g_cap, (int64_t)m * m);
+    if (rc) return rc;
+    rc = ensure(c->d_delta, c->delta_cap, n_cand);
+    if (rc) return rc;
+    if (!c->d_win_id) {
+        HIPCHK(hipMalloc((void**)&c->d_win_id, sizeof(int32_t) * 8));
+        HIPCHK(hipMalloc((void**)&c->d_win_off, sizeof(int32_t) * 8));
+        HIPCHK(hipMalloc((void**)&c->d_win_rev, 8));
+    }
+    int32_t win_id[8], win_off[8]; uint8_t win_rev[8];
+    for (int64_t j = 0; j < k; j++) {
+        win_id[j] = c->h_arr_id[(size_t)(first + j)];
+        win_rev[j] = c->h_arr_rev[(size_t)(first + j)];
+        win_off[j] = c->h_arr_pos[(size_t)(first + j)] - p0;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_win_id, win_id, sizeof(int32_t) * (size_t)k, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_win_off, win_off, sizeof(int32_t) * (size_t)k, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_win_rev, win_rev, (size_t)k, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));       // stack arrays above
+    {
+        Timed t(c, F_P2_WINDOW_G, 8.0 * (double)m * (double)(c->n_arr - m));
+        launch_p2_window_G(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, p0, m, c->d_H, c->d_G, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    {
+        Timed t(c, F_P2_WINDOW_DELTA, 8.0 * (double)n_cand * (0.5 * (double)m * (double)(m - 1) + (double)m));
+        launch_p2_window_delta(c->dM2, c->ld2, (int)c->n_arr, m, (int)k, c->d_win_id, c->d_win_rev, c->d_win_off,
+                               c->d_scaf_start, c->d_scaf_len, c->d_orders, c->d_orients, (int)c->n_orders,
+                               (int)c->n_orients, c->d_H, c->d_G, c->d_delta, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(delta_out, c->d_delta, sizeof(double) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return HICMI_OK;
 }

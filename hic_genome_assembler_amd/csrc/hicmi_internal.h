@@ -35,4 +35,23 @@ void launch_p2_score_exact(const double* M2, int64_t ld2, const int32_t* perms, 
 void launch_p2_score(const double* M2, int64_t ld2, const int32_t* perms, int n_cand, int n_used, const double* H,
                      double inv_total_unused, double total, double* scores, hipStream_t s);
 
+void launch_p2_total_perm(const double* M2, int64_t ld2, const int32_t* d_perm, int n, double* T, double* total,
+                          hipStream_t s);
+
+// k_part2_search.hip
+void launch_arr_materialize(const int32_t* arr_id, const uint8_t* arr_rev, const int32_t* arr_pos, int S,
+                            const int32_t* scaf_start, const int32_t* scaf_len, int n_arr, int32_t* pos2sel,
+                            hipStream_t s);
+void launch_p2_score_insert(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const int32_t* arr_pos,
+                            int S, int new_start, int new_len, const double* H, double total, double* scores,
+                            hipStream_t s);
+void launch_p2_score_arr(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const double* H,
+                         double total, double* score, hipStream_t s);
+void launch_p2_window_G(const double* M2, int64_t ld2, const int32_t* pos2sel, int n, int p0, int m, const double* H,
+                        double* G, hipStream_t s);
+void launch_p2_window_delta(const double* M2, int64_t ld2, int n, int m, int k, const int32_t* win_id,
+                            const uint8_t* win_rev, const int32_t* win_off, const int32_t* scaf_start,
+                            const int32_t* scaf_len, const int8_t* orders, const uint8_t* orients, int n_ord, int n_ori,
+                            const double* H, const double* G, double* delta, hipStream_t s);
+
 }  // namespace hicmi

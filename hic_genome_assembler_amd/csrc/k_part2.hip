@@ -146,6 +146,15 @@ void launch_p2_total(const double* M2, int64_t ld2, int n, double* T, double* to
     hipLaunchKernelGGL(k_p2_total_exact, dim3(1), dim3(64), 0, s, T, n, total);
 }
 
+void launch_p2_total_perm(const double* M2, int64_t ld2, const int32_t* d_perm, int n, double* T, double* total,
+                          hipStream_t s)
+{
+    size_t lds = (((size_t)n * sizeof(int32_t)) + 15) & ~(size_t)15;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_diag_sums), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3((n - 1 + 255) / 256, 1), dim3(256), lds, s, M2, ld2, d_perm, n, T);
+    hipLaunchKernelGGL(k_p2_total_exact, dim3(1), dim3(64), 0, s, T, n, total);
+}
+
 void launch_p2_score_exact(const double* M2, int64_t ld2, const int32_t* perms, int n_cand, int n_used, double total,
                            double* T, double* scores, hipStream_t s)
 {

@@ -1,0 +1,234 @@
+// k_part2_search.hip - Part 2 search steps with the candidates ENUMERATED ON THE DEVICE
+// (orderGenome.py:332-372 checkAllScores, :432-473 bruteForceBestScore, :495-549 scanOrdering).
+//
+// The reference builds, for every candidate, a Python list of bin indices and a gathered copy of
+// the matrix.  Here a chromosome's sub-matrix is selected once (hicmi_p2_select); its scaffolds are
+// contiguous ranges of that selection (the "layout"); the current order/orientation is a short
+// list of (scaffold, reversed) pairs (the "arrangement") expanded on the device into
+// pos2sel[position] -> selection index.  Candidates are then described by a few integers:
+//   insertion : (gap, reversed) of one new scaffold          -> 2(S+1) candidates, scored directly
+//   window    : (order index, orientation index) into the enumeration tables of k scaffolds
+//               -> k!/2 * 2^k candidates, scored INCREMENTALLY:
+//       score(c) * total = [pairs outside the window]                      same for every c
+//                        + sum_t G[x_t][t]                                  window bin x_t at slot t
+//                        + sum_{s<t} M[u_s][u_t] * w(t-s)                   pairs inside the window
+//       with G[x][t] = sum_{q outside} M[u_x][bin at q] * w(|p0+t-q|),  w(d) = H[n-1] - H[d-1].
+//     G is an (m x m) table per window (m = bins in the window): m*m*(n-m) multiply-adds instead
+//     of (#candidates * n^2/2).  Only differences between candidates of one window are used by the
+//     host, and the winners are re-scored literally (k_p2_diag_sums), so rounding of this
+//     decomposition never reaches an output.
+#include "hicmi_internal.h"
+
+namespace hicmi {
+
+__device__ __forceinline__ double wave_sum_s(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// pos2sel[q] for the arrangement (arr_id, arr_rev) with prefix positions arr_pos[0..S]
+__global__ __launch_bounds__(256) void k_arr_materialize(const int32_t* __restrict__ arr_id,
+                                                         const uint8_t* __restrict__ arr_rev,
+                                                         const int32_t* __restrict__ arr_pos, int S,
+                                                         const int32_t* __restrict__ scaf_start,
+                                                         const int32_t* __restrict__ scaf_len, int n_arr,
+                                                         int32_t* __restrict__ pos2sel)
+{
+    int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_arr) return;
+    int lo = 0, hi = S;                                   // largest j with arr_pos[j] <= q
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (arr_pos[mid] <= q) lo = mid; else hi = mid;
+    }
+    int sc = arr_id[lo], off = q - arr_pos[lo], len = scaf_len[sc];
+    pos2sel[q] = scaf_start[sc] + (arr_rev[lo] ? len - 1 - off : off);
+}
+
+void launch_arr_materialize(const int32_t* arr_id, const uint8_t* arr_rev, const int32_t* arr_pos, int S,
+                            const int32_t* scaf_start, const int32_t* scaf_len, int n_arr, int32_t* pos2sel,
+                            hipStream_t s)
+{
+    if (n_arr <= 0) return;
+    hipLaunchKernelGGL(k_arr_materialize, dim3((n_arr + 255) / 256), dim3(256), 0, s, arr_id, arr_rev, arr_pos, S,
+                       scaf_start, scaf_len, n_arr, pos2sel);
+}
+
+// closed-form objective of the permutation held in LDS (same arithmetic as k_p2_score)
+__device__ __forceinline__ double score_lds_perm(const double* __restrict__ M2, int64_t ld2, const int32_t* p, int n,
+                                                 const double* __restrict__ H, double* s_w)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double hn = H[n - 1];
+    double acc = 0.0;
+    for (int a = wave; a < n - 1; a += 4) {
+        const double* __restrict__ row = M2 + (int64_t)p[a] * ld2;
+        for (int b = a + 1 + lane; b < n; b += 64) acc += row[p[b]] * (hn - H[b - a - 1]);
+    }
+    acc = wave_sum_s(acc);
+    if (lane == 0) s_w[wave] = acc;
+    __syncthreads();
+    return (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+// checkAllScores candidates: block = (gap g, reversed f); perm = arrangement with the new scaffold
+// spliced in at position arr_pos[g].
+__global__ __launch_bounds__(256) void k_p2_score_insert(const double* __restrict__ M2, int64_t ld2,
+                                                         const int32_t* __restrict__ pos2sel, int n_arr,
+                                                         const int32_t* __restrict__ arr_pos, int new_start,
+                                                         int new_len, const double* __restrict__ H, double total,
+                                                         double* __restrict__ scores)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int32_t* p = reinterpret_cast<int32_t*>(smem);
+    __shared__ double s_w[4];
+    const int g = blockIdx.x >> 1, f = blockIdx.x & 1;
+    const int P = arr_pos[g], n = n_arr + new_len;
+    for (int q = threadIdx.x; q < n; q += 256) {
+        int v;
+        if (q < P) v = pos2sel[q];
+        else if (q < P + new_len) { int e = q - P; v = new_start + (f ? new_len - 1 - e : e); }
+        else v = pos2sel[q - new_len];
+        p[q] = v;
+    }
+    __syncthreads();
+    double sum = score_lds_perm(M2, ld2, p, n, H, s_w);
+    if (threadIdx.x == 0) scores[blockIdx.x] = sum / total;
+}
+
+void launch_p2_score_insert(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const int32_t* arr_pos,
+                            int S, int new_start, int new_len, const double* H, double total, double* scores,
+                            hipStream_t s)
+{
+    size_t lds = (((size_t)(n_arr + new_len) * sizeof(int32_t)) + 15) & ~(size_t)15;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_score_insert), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_p2_score_insert, dim3(2 * (S + 1)), dim3(256), lds, s, M2, ld2, pos2sel, n_arr, arr_pos,
+                       new_start, new_len, H, total, scores);
+}
+
+// score of the arrangement itself (one candidate): perm = pos2sel
+__global__ __launch_bounds__(256) void k_p2_score_arr(const double* __restrict__ M2, int64_t ld2,
+                                                      const int32_t* __restrict__ pos2sel, int n_arr,
+                                                      const double* __restrict__ H, double total,
+                                                      double* __restrict__ score)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int32_t* p = reinterpret_cast<int32_t*>(smem);
+    __shared__ double s_w[4];
+    for (int q = threadIdx.x; q < n_arr; q += 256) p[q] = pos2sel[q];
+    __syncthreads();
+    double sum = score_lds_perm(M2, ld2, p, n_arr, H, s_w);
+    if (threadIdx.x == 0) score[0] = sum / total;
+}
+
+void launch_p2_score_arr(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const double* H,
+                         double total, double* score, hipStream_t s)
+{
+    size_t lds = (((size_t)n_arr * sizeof(int32_t)) + 15) & ~(size_t)15;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_score_arr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_p2_score_arr, dim3(1), dim3(256), lds, s, M2, ld2, pos2sel, n_arr, H, total, score);
+}
+
+// ---- window: G table ----------------------------------------------------------------------------
+// block x = window bin at current position p0+x; its row of M2 restricted to the positions outside
+// [p0, p0+m) is staged through LDS in tiles; lane t accumulates G[x][t].
+static constexpr int G_TILE = 4096;
+
+__global__ __launch_bounds__(256) void k_p2_window_G(const double* __restrict__ M2, int64_t ld2,
+                                                     const int32_t* __restrict__ pos2sel, int n, int p0, int m,
+                                                     const double* __restrict__ H, double* __restrict__ G)
+{
+    __shared__ double vals[G_TILE];
+    const int x = blockIdx.x, tid = threadIdx.x;
+    const double* __restrict__ row = M2 + (int64_t)pos2sel[p0 + x] * ld2;
+    const double hn = H[n - 1];
+    const int n_out = n - m, p1 = p0 + m;
+    // per-lane accumulators for t = tid, tid+256, ... (m is at most a few thousand)
+    for (int t0 = 0; t0 < m; t0 += 256) {
+        const int t = t0 + tid;
+        double acc = 0.0;
+        for (int base = 0; base < n_out; base += G_TILE) {
+            const int cnt = n_out - base < G_TILE ? n_out - base : G_TILE;
+            __syncthreads();
+            for (int e = tid; e < cnt; e += 256) {
+                int qq = base + e;
+                int q = qq < p0 ? qq : qq + m;            // skip the window
+                vals[e] = row[pos2sel[q]];
+            }
+            __syncthreads();
+            if (t < m) {
+                const int pt = p0 + t;
+                for (int e = 0; e < cnt; e++) {
+                    int qq = base + e;
+                    int q = qq < p0 ? qq : qq + m;
+                    int d = q < p0 ? pt - q : q - pt;     // q < p0 <= pt  or  pt < p1 <= q
+                    acc += vals[e] * (hn - H[d - 1]);
+                }
+            }
+        }
+        if (t < m) G[(int64_t)x * m + t] = acc;
+    }
+    (void)p1;
+}
+
+void launch_p2_window_G(const double* M2, int64_t ld2, const int32_t* pos2sel, int n, int p0, int m, const double* H,
+                        double* G, hipStream_t s)
+{
+    if (m <= 0) return;
+    hipLaunchKernelGGL(k_p2_window_G, dim3(m), dim3(256), 0, s, M2, ld2, pos2sel, n, p0, m, H, G);
+}
+
+// ---- window: per-candidate delta -----------------------------------------------------------------
+// block = candidate (order o, orientation r) of the k window scaffolds.  Slot j of the candidate holds
+// window scaffold jj = orders[o][j] laid down reversed iff orients[r][j]; a bin's window-local index
+// x is its offset inside the CURRENT window layout (that is how G is indexed).
+__global__ __launch_bounds__(64) void k_p2_window_delta(
+    const double* __restrict__ M2, int64_t ld2, int n, int m, int k, const int32_t* __restrict__ win_id,
+    const uint8_t* __restrict__ win_rev, const int32_t* __restrict__ win_off, const int32_t* __restrict__ scaf_start,
+    const int32_t* __restrict__ scaf_len, const int8_t* __restrict__ orders, const uint8_t* __restrict__ orients,
+    int n_ori, const double* __restrict__ H, const double* __restrict__ G, double* __restrict__ delta)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int32_t* useq = reinterpret_cast<int32_t*>(smem);          // selection index at slot t
+    int32_t* xseq = useq + m;                                   // window-local index at slot t
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int8_t* __restrict__ ord = orders + (int64_t)(c / n_ori) * k;
+    const uint8_t* __restrict__ ori = orients + (int64_t)(c % n_ori) * k;
+    int slot_off[9];
+    slot_off[0] = 0;
+    for (int j = 0; j < k; j++) slot_off[j + 1] = slot_off[j] + scaf_len[win_id[ord[j]]];
+    for (int t = lane; t < m; t += 64) {
+        int j = 0;
+        while (j + 1 < k && slot_off[j + 1] <= t) j++;
+        const int jj = ord[j], sc = win_id[jj], len = scaf_len[sc];
+        const int ep = t - slot_off[j];
+        const int e = ori[j] ? len - 1 - ep : ep;              // offset inside the scaffold, selection order
+        useq[t] = scaf_start[sc] + e;
+        xseq[t] = win_off[jj] + (win_rev[jj] ? len - 1 - e : e);
+    }
+    __syncthreads();
+    const double hn = H[n - 1];
+    double acc = 0.0;
+    for (int t = lane; t < m; t += 64) acc += G[(int64_t)xseq[t] * m + t];
+    for (int s = 0; s < m - 1; s++) {
+        const double* __restrict__ row = M2 + (int64_t)useq[s] * ld2;
+        for (int t = s + 1 + lane; t < m; t += 64) acc += row[useq[t]] * (hn - H[t - s - 1]);
+    }
+    acc = wave_sum_s(acc);
+    if (lane == 0) delta[c] = acc;
+}
+
+void launch_p2_window_delta(const double* M2, int64_t ld2, int n, int m, int k, const int32_t* win_id,
+                            const uint8_t* win_rev, const int32_t* win_off, const int32_t* scaf_start,
+                            const int32_t* scaf_len, const int8_t* orders, const uint8_t* orients, int n_ord, int n_ori,
+                            const double* H, const double* G, double* delta, hipStream_t s)
+{
+    size_t lds = (((size_t)m * 2 * sizeof(int32_t)) + 15) & ~(size_t)15;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_window_delta), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_p2_window_delta, dim3(n_ord * n_ori), dim3(64), lds, s, M2, ld2, n, m, k, win_id, win_rev,
+                       win_off, scaf_start, scaf_len, orders, orients, n_ori, H, G, delta);
+}
+
+}  // namespace hicmi

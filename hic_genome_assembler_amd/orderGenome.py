@@ -1,13 +1,20 @@
 """Part 2 (order + orient scaffolds inside each chromosome) on MI355X: drop-in for the reference
 module of the same name (/root/reference/HIC_ASSEMBLER/orderGenome.py, OG below).
 
-Same ``runPipeline`` signature, same input/output files, same search (brute force over the
-largest scaffolds, greedy insertion of the rest, sliding-window re-permutation to a fixed point)
-with the same enumeration order and first-strict-maximum tie-breaking.  What changes is where the
-objective is evaluated: the reference gathers a permuted copy of the matrix with ``numpy.ix_`` and
-runs a Numba loop once per candidate (OG:348,358,463,534); here every candidate of a step is one
-row of an index array scored in one launch of k_p2_score (hicmi_p2_score), reading the
-chromosome's sub-matrix - resident in HBM - through the permutation.  fp64 on the GPU.
+Same ``runPipeline`` signature, same input/output files and the same search - brute force over the
+largest scaffolds, greedy insertion of the rest, sliding-window re-permutation to a fixed point -
+with the reference's enumeration order and first-strict-maximum tie-breaking.  What changes is where
+candidates live and how they are scored:
+
+* a chromosome's contacts are selected ONCE into a device sub-matrix; each scaffold is a contiguous
+  range of it (the layout) and an order/orientation is a list of (scaffold, reversed) pairs (the
+  arrangement) - the reference instead rebuilds a gathered matrix and an index dictionary for every
+  step (giveNewAdjMat, OG:296-308) and a Python index list per candidate;
+* the candidates of a step are enumerated by the kernels themselves (k_part2_search.hip):
+  2(S+1) insertions per launch, k!/2 * 2^k window candidates per launch with the incremental form
+  of the objective;
+* the few candidates that can win a step are re-scored in the reference's exact operation order
+  (k_p2_diag_sums), because `cost > bestCost` is decided at the last bit (see first_strict_max).
 """
 from __future__ import annotations
 
@@ -19,6 +26,9 @@ import numpy as np
 from . import _lib
 from .hostio import Bin, initiateLoci, read_contact_matrix  # noqa: F401
 
+SCORE_HOOK = None      # tests: called with the fast scores of every step, in enumeration order
+NEAR_TOP = 1e-9        # relative band around a step's best fast score that is re-scored literally
+
 
 # ------------------------------------------------------------------------------------------------
 class GenomeMatrix:
@@ -26,60 +36,135 @@ class GenomeMatrix:
 
     def __init__(self, ctx: _lib.Context):
         self.ctx = ctx
+        self.chrom = None              # ChromosomeLayout currently selected on the device
+        self._bin_index = None
+        self._bin_index_src = None
 
     def __len__(self):
         return self.ctx.n
 
+    def bin_index(self, binList):
+        if self._bin_index is None or self._bin_index_src is not binList:
+            self._bin_index = {b.ID: i for i, b in enumerate(binList)}
+            self._bin_index_src = binList
+        return self._bin_index
+
+
+class ChromosomeLayout:
+    """All scaffolds of one chromosome selected on the device: scaffold s <-> a contiguous range of
+    the selection holding its bins in ascending-ID ('+') order."""
+
+    def __init__(self, matrix: GenomeMatrix, scaffolds, binList):
+        self.ctx = matrix.ctx
+        where = matrix.bin_index(binList)
+        self.sid, self.start, self.length = {}, [], []
+        sel, pos = [], 0
+        for s in scaffolds:
+            bins = sorted(s.binList)
+            self.sid[s.name] = len(self.start)
+            self.start.append(pos)
+            self.length.append(len(bins))
+            sel += [where[b] for b in bins]
+            pos += len(bins)
+        self.n = pos
+        self.ctx.p2_select(sel)
+        self.ctx.p2_layout(self.start, self.length)
+        self._tables_k = None
+
+    def covers(self, scaffs):
+        return all(s.name in self.sid for s in scaffs)
+
+    def describe(self, scaffs):
+        """(ids, rev) of an arrangement; rev = 1 for '-'."""
+        ids = np.fromiter((self.sid[s.name] for s in scaffs), dtype=np.int32, count=len(scaffs))
+        rev = np.fromiter((1 if s.orientation == "-" else 0 for s in scaffs), dtype=np.uint8, count=len(scaffs))
+        return ids, rev
+
+    def positions(self, sid, rev):
+        """Selection indices of one scaffold laid down forward / reversed."""
+        a = np.arange(self.start[sid], self.start[sid] + self.length[sid], dtype=np.int32)
+        return a[::-1] if rev else a
+
+    def node_row(self, ids, rev):
+        return np.concatenate([self.positions(int(i), int(r)) for i, r in zip(ids, rev)]) if len(ids) else \
+            np.zeros(0, np.int32)
+
+    def tables(self, k):
+        if self._tables_k != k:
+            orders, orients = _enumeration(k)
+            self.ctx.p2_window_tables(np.asarray(orders, dtype=np.int8),
+                                      np.asarray([[1 if sg == "-" else 0 for sg in r] for r in orients], dtype=np.uint8))
+            self._tables_k = k
+        return _enumeration(k)
+
 
 class SubMatrix:
-    """The device-side selection made by giveNewAdjMat (OG:296-308)."""
+    """What giveNewAdjMat returns here: the scaffolds of ``scaffList`` in their order and
+    orientation AT CREATION (that order fixes the rounding of ``total``, OG:343/448/506), plus a
+    cache of literal scores evaluated under that total."""
 
-    def __init__(self, ctx: _lib.Context, n: int):
-        self.ctx = ctx
-        self.n = n
+    def __init__(self, layout: ChromosomeLayout, scaffList):
+        self.layout = layout
+        self.ctx = layout.ctx
+        self.ids, self.rev = layout.describe(scaffList)
+        self.n = int(sum(layout.length[i] for i in self.ids))
         self._total = None
+        self.exact = {}                # node-row bytes -> literal score under this total
 
     def __len__(self):
         return self.n
 
     def total(self) -> float:
-        """Sum of everything above the diagonal (OG:343, 448, 506)."""
+        """Sum of everything above the diagonal with the reference's rounding (OG:343, 448, 506)."""
         if self._total is None:
-            self._total = 0.0 if self.n < 2 else self.ctx.p2_total()
+            if self.n < 2:
+                self._total = 0.0
+            else:
+                self.ctx.p2_set_arrangement(self.ids, self.rev)
+                self._total = self.ctx.p2_arrangement_total()
         return self._total
 
-    def scores(self, perms) -> np.ndarray:
-        """costFunction_numba (OG:184-191) of every row of ``perms`` (positions into this selection),
-        closed form in fp64 (k_p2_score)."""
-        perms = np.ascontiguousarray(perms, dtype=np.int32)
-        if perms.shape[1] < 2:
-            return np.zeros(perms.shape[0])             # range(1, 1) is empty: cost 0.0
-        return self.ctx.p2_score(perms, self.total())
+    def first_strict_max(self, fast, floor, row_of):
+        """The reference's ``if cost > bestCost`` scan over a step's candidates in enumeration order
+        (OG:349,359,464,535), starting from ``bestCost = floor``: returns (index, cost) of the winner
+        or (-1, floor).
 
-    def first_strict_max(self, perms, floor):
-        """The reference's ``if cost > bestCost`` scan over the candidates in enumeration order
-        (OG:349,359,464,535), starting from ``bestCost = floor``: returns (index, cost) of the
-        winner or (-1, floor).  Those comparisons are decided at the last bit (the same arrangement
-        under two differently rounded totals differs by an ulp), so every candidate whose fast
-        score is within 1e-9 of the step's best is re-scored in the reference's exact operation
-        order (k_p2_diag_sums / hicmi_p2_score_exact) and the decision uses those values."""
-        perms = np.ascontiguousarray(perms, dtype=np.int32)
-        fast = self.scores(perms)
+        ``fast`` are the closed-form fp64 scores of all candidates; ``row_of(c)`` gives candidate c's
+        bin order as selection indices.  The reference's comparisons are decided at the last bit -
+        the same arrangement scored under two differently rounded totals (OG:506 vs OG:343) differs
+        by an ulp, and that decides whether a pass "improves" - so every candidate within 1e-9 of
+        the step's best is re-scored in the reference's exact operation order
+        (hicmi_p2_score_exact) and the decision is taken on those values.  Identical bin orders
+        (flipping a one-bin scaffold) share one literal evaluation and tie exactly, as they do in
+        the reference."""
+        fast = np.asarray(fast, dtype=np.float64)
+        if SCORE_HOOK is not None:
+            SCORE_HOOK(fast)
         ok = np.isfinite(fast)
         if not ok.any():
             return -1, floor
         top = max(float(fast[ok].max()), float(floor))
-        near = np.flatnonzero(ok & (fast >= top - abs(top) * 1e-9))
+        near = np.flatnonzero(ok & (fast >= top - abs(top) * NEAR_TOP))
         if len(near) == 0:
             return -1, floor
-        if perms.shape[1] < 2:
-            exact = np.zeros(len(near))
-        else:
-            exact = self.ctx.p2_score_exact(perms[near], self.total())
+        rows = [np.ascontiguousarray(row_of(int(c)), dtype=np.int32) for c in near]
+        keys = [r.tobytes() for r in rows]
+        todo = {}
+        for r, key in zip(rows, keys):
+            if key not in self.exact and key not in todo:
+                todo[key] = r
+        if todo:
+            if len(rows[0]) < 2:
+                vals = np.zeros(len(todo))                       # range(1, 1) is empty: cost 0.0
+            else:
+                vals = self.ctx.p2_score_exact(np.stack(list(todo.values())), self.total())
+            for key, v in zip(todo, vals):
+                self.exact[key] = float(v)
         pick, best = -1, floor
-        for c, v in zip(near, exact):
+        for c, key in zip(near, keys):
+            v = self.exact[key]
             if v > best:
-                pick, best = int(c), float(v)
+                pick, best = int(c), v
         return pick, best
 
 
@@ -161,16 +246,14 @@ def pullScaffolds(puller, pullee, scaffsToPull):
 
 
 def giveNewAdjMat(matrix: GenomeMatrix, scaffList, binList):
-    """OG:296-308: select the bins of ``scaffList`` (in list order, current orientation) on the
-    device; returns the selection and {binID: position in the selection}."""
-    nodes = [n for s in scaffList for n in s.binList]
-    orderDict = {b: i for i, b in enumerate(nodes)}
-    where = getattr(matrix, "_bin_index", None)
-    if where is None or getattr(matrix, "_bin_index_src", None) is not binList:
-        where = {b.ID: i for i, b in enumerate(binList)}
-        matrix._bin_index, matrix._bin_index_src = where, binList
-    matrix.ctx.p2_select([where[b] for b in nodes])
-    return SubMatrix(matrix.ctx, len(nodes)), orderDict
+    """OG:296-308.  The device already holds the chromosome's sub-matrix (selected once by
+    orderChromosome); this records ``scaffList``'s order/orientation - which fixes how ``total`` is
+    rounded - and returns it with {binID: index in that order}.  Called outside orderChromosome it
+    selects just these scaffolds."""
+    if matrix.chrom is None or not matrix.chrom.covers(scaffList):
+        matrix.chrom = ChromosomeLayout(matrix, scaffList, binList)
+    orderDict = {b: i for i, b in enumerate(n for s in scaffList for n in s.binList)}
+    return SubMatrix(matrix.chrom, scaffList), orderDict
 
 
 def reorderScaffList(orderList, orientationList, scaffDict):
@@ -186,15 +269,16 @@ def reorderScaffList(orderList, orientationList, scaffDict):
 
 
 def costFunction(matrix, total):
-    """OG:323-330 for an explicit (already permuted) host matrix: uploaded and scored on the GPU.
-    Kept for callers of the reference's function-level API; the pipeline itself batches."""
+    """OG:323-330 for an explicit (already permuted) host matrix: uploaded and scored on the GPU in
+    the reference's operation order.  Kept for callers of the reference's function-level API."""
     m = np.ascontiguousarray(np.asarray(matrix, dtype=np.float64))
+    if len(m) < 2:
+        return 0.0
     with _lib.Context(0) as ctx:
         ctx.set_contacts(m)
-        ctx.p2_select(np.arange(len(m), dtype=np.int32))
-        if len(m) < 2:
-            return 0.0
-        return float(ctx.p2_score(np.arange(len(m), dtype=np.int32)[None, :], float(total))[0])
+        ident = np.arange(len(m), dtype=np.int32)
+        ctx.p2_select(ident)
+        return float(ctx.p2_score_exact(ident[None, :], float(total))[0])
 
 
 costFunction_numba = costFunction      # OG:184-191
@@ -249,17 +333,44 @@ _ENUM_CACHE = {}
 
 
 def _enumeration(k):
-    """(orders, orientations) over positions 0..k-1, cached."""
+    """(orders over slots 0..k-1, orientations), cached.  orders[0] is the identity."""
     if k not in _ENUM_CACHE:
         orders = removeReverseDuplicates(permutations(list(range(k)), [], 0))
-        _ENUM_CACHE[k] = (orders, plusMinusPerms(list(range(k))))
-    return _ENUM_CACHE[k]
+        orients = plusMinusPerms(list(range(k)))
+        _ENUM_CACHE[k] = (orders, orients, {tuple(r): i for i, r in enumerate(orients)})
+    return _ENUM_CACHE[k][0], _ENUM_CACHE[k][1]
 
 
-def _positions(scaff, orderDict, orientation):
-    """Selection positions of a scaffold's bins when it is laid down with ``orientation``."""
-    pos = [orderDict[b] for b in scaff.binList]
-    return pos if scaff.orientation == orientation else pos[::-1]
+def _orient_index(k, signs):
+    _enumeration(k)
+    return _ENUM_CACHE[k][2][tuple(signs)]
+
+
+def _window_scores(view: SubMatrix, arrangement, first, k, known_fast=None):
+    """Fast scores of all k!/2 * 2^k candidates for the window arrangement[first:first+k] (everything
+    else fixed), from one hicmi_p2_score_window launch.  Returns (fast, row_of)."""
+    layout, ctx = view.layout, view.ctx
+    orders, orients = layout.tables(k)
+    ids, rev = layout.describe(arrangement)
+    total = view.total()
+    ctx.p2_set_arrangement(ids, rev)
+    delta = ctx.p2_score_window(first, k)
+    if k == len(arrangement):
+        fast = delta / total                              # nothing outside the window
+    else:
+        c0 = _orient_index(k, [s.orientation for s in arrangement[first:first + k]])   # orders[0] = identity
+        base = ctx.p2_arrangement_score(total) if known_fast is None else known_fast
+        fast = base + (delta - delta[c0]) / total
+    n_ori = len(orients)
+    head = layout.node_row(ids[:first], rev[:first])
+    tail = layout.node_row(ids[first + k:], rev[first + k:])
+    win = ids[first:first + k]
+
+    def row_of(c):
+        o, r = orders[c // n_ori], orients[c % n_ori]
+        mid = [layout.positions(int(win[j]), sg == "-") for j, sg in zip(o, r)]
+        return np.concatenate([head] + mid + [tail])
+    return fast, row_of
 
 
 # ---- search ---------------------------------------------------------------------------------------
@@ -274,14 +385,8 @@ def bruteForceBestScore(sObjList, scaffDict, matrix: SubMatrix, orderDict):
               + ",".join(str(e) for e in names))
         return [names[i] for i in orders[0]], list(orients[0]), 0.0
     print("Initial permutations to test " + str(len(orders) * len(orients)) + "...")
-    fwd = {s.name: np.asarray(_positions(s, orderDict, "+"), dtype=np.int32) for s in sObjList}
-    rev = {nm: p[::-1] for nm, p in fwd.items()}
-    rows = []
-    for o in orders:
-        onames = [names[i] for i in o]
-        for r in orients:
-            rows.append(np.concatenate([fwd[nm] if sg == "+" else rev[nm] for nm, sg in zip(onames, r)]))
-    best, best_c = matrix.first_strict_max(np.stack(rows), 0.)     # first strict maximum above 0. (OG:464)
+    fast, row_of = _window_scores(matrix, sObjList, 0, k)
+    best, best_c = matrix.first_strict_max(fast, 0., row_of)          # first strict maximum above 0. (OG:464)
     # the enumeration leaves every scaffold in the last candidate's orientation (OG:459)
     reorderScaffList([names[i] for i in orders[-1]], orients[-1], scaffDict)
     if best < 0:
@@ -293,19 +398,32 @@ def bruteForceBestScore(sObjList, scaffDict, matrix: SubMatrix, orderDict):
 def checkAllScores(adjMat: SubMatrix, orderDict, orderedScaffs, scaffToCheck):
     """OG:332-372: try the scaffold at every gap, both orientations.  The scaffold is flipped once
     per gap and stays flipped, so the orientation tried first alternates with the gap index."""
+    layout, ctx = adjMat.layout, adjMat.ctx
     gaps = len(orderedScaffs) + 1
-    placed = [np.asarray([orderDict[b] for b in s.binList], dtype=np.int32) for s in orderedScaffs]
-    cur = np.asarray([orderDict[b] for b in scaffToCheck.binList], dtype=np.int32)
+    total = adjMat.total()
     flip = {"+": "-", "-": "+"}
-    o = scaffToCheck.orientation
-    rows, tags = [], []
+    new_id = layout.sid[scaffToCheck.name]
+    ids, rev = layout.describe(orderedScaffs)
+    tags, o = [], scaffToCheck.orientation
     for i in range(gaps):
-        for _half in range(2):
-            rows.append(np.concatenate(placed[:i] + [cur] + placed[i:]))
-            tags.append((i, o))
-            if _half == 0:
-                cur, o = cur[::-1], flip[o]
-    pick, bestCost = adjMat.first_strict_max(np.stack(rows), 0.)
+        tags += [(i, o), (i, flip[o])]
+        o = flip[o]
+    n_all = adjMat.n
+    if n_all < 2:
+        fast = np.zeros(2 * gaps)
+    elif len(ids) == 0:
+        rows = np.stack([layout.positions(new_id, sg == "-") for _i, sg in tags])
+        fast = ctx.p2_score(rows, total)
+    else:
+        ctx.p2_set_arrangement(ids, rev)
+        by_gap_rev = ctx.p2_score_insertions(new_id, total)             # [2*gap + (orientation == '-')]
+        fast = np.array([by_gap_rev[2 * i + (1 if sg == "-" else 0)] for i, sg in tags])
+    pieces = [layout.positions(int(i), int(r)) for i, r in zip(ids, rev)]
+
+    def row_of(c):
+        i, sg = tags[c]
+        return np.concatenate(pieces[:i] + [layout.positions(new_id, sg == "-")] + pieces[i:])
+    pick, bestCost = adjMat.first_strict_max(fast, 0., row_of)
     bestGap, bestOrient = tags[pick] if pick >= 0 else (0, "+")
     if gaps % 2 == 1:                                   # one flip per gap (OG:356)
         scaffToCheck.flipOrientation()
@@ -332,35 +450,32 @@ def scanOrdering(orderedScaffolds, scaffoldDict, orderDict, matrix: GenomeMatrix
     order/orientation of the window is scored on the WHOLE chromosome; repeat until a full pass
     brings no improvement."""
     adjMat, orderDict = giveNewAdjMat(matrix, orderedScaffolds, binList)
-    adjMat.total()
+    total = adjMat.total()
     bestOrder = [s.name for s in orderedScaffolds]
     bestOrientation = [s.orientation for s in orderedScaffolds]
     roundNumber = 0
     w = scanScaffolds
     orders, orients = _enumeration(w)
+    cur_fast = None                                     # fast score of the current arrangement
     while True:
         improved = False
         print("Working on round " + str(roundNumber + 1) + " of final step...")
         for i in range(0, len(orderedScaffolds) - w + 1):
-            window = orderedScaffolds[i:i + w]
-            head = [np.asarray([orderDict[b] for b in s.binList], dtype=np.int32) for s in orderedScaffolds[:i]]
-            tail = [np.asarray([orderDict[b] for b in s.binList], dtype=np.int32) for s in orderedScaffolds[i + w:]]
-            head = np.concatenate(head) if head else np.zeros(0, np.int32)
-            tail = np.concatenate(tail) if tail else np.zeros(0, np.int32)
-            fwd = [np.asarray(_positions(s, orderDict, "+"), dtype=np.int32) for s in window]
-            rev = [p[::-1] for p in fwd]
-            rows = []
-            for o in orders:
-                for r in orients:
-                    rows.append(np.concatenate([head] + [fwd[j] if sg == "+" else rev[j] for j, sg in zip(o, r)] + [tail]))
-            pick, bestCost = adjMat.first_strict_max(np.stack(rows), bestCost)   # strict '>' vs the global best (OG:535)
+            if cur_fast is None:
+                ids, rev = adjMat.layout.describe(orderedScaffolds)
+                adjMat.ctx.p2_set_arrangement(ids, rev)
+                cur_fast = adjMat.ctx.p2_arrangement_score(total)
+            fast, row_of = _window_scores(adjMat, orderedScaffolds, i, w, known_fast=cur_fast)
+            pick, bestCost = adjMat.first_strict_max(fast, bestCost, row_of)   # strict '>' vs the global best (OG:535)
             if pick >= 0:
                 improved = True
                 o, r = orders[pick // len(orients)], orients[pick % len(orients)]
+                window = orderedScaffolds[i:i + w]
                 names = [s.name for s in orderedScaffolds]
                 outside = {s.name: s.orientation for s in orderedScaffolds}
                 bestOrder = names[:i] + [window[j].name for j in o] + names[i + w:]
                 bestOrientation = ([outside[nm] for nm in names[:i]] + list(r) + [outside[nm] for nm in names[i + w:]])
+                cur_fast = float(fast[pick])
             orderedScaffolds, _nodes = reorderScaffList(bestOrder, bestOrientation, scaffoldDict)
         roundNumber += 1
         if not improved:
@@ -378,6 +493,7 @@ def orderChromosome(chromGroup, matrix: GenomeMatrix, binList, nScaffolds=6, sca
     if scanScaffolds > nScaffolds:
         scanScaffolds = nScaffolds
     scaffoldList, scaffoldDict = initiateBinsAndScaffolds(chromGroup)
+    matrix.chrom = ChromosomeLayout(matrix, scaffoldList, binList)      # one selection for the whole chromosome
     orderedScaffolds, scaffoldList = pullScaffolds([], scaffoldList, nScaffolds)
     adjMat, orderDict = giveNewAdjMat(matrix, orderedScaffolds, binList)
     bfOrder, bfOrient, _bfScore = bruteForceBestScore(orderedScaffolds, scaffoldDict, adjMat, orderDict)

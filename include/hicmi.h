@@ -128,6 +128,38 @@ int hicmi_p2_score(hicmi_ctx *ctx, const int32_t *perms, int64_t n_cand, int64_t
 int hicmi_p2_score_exact(hicmi_ctx *ctx, const int32_t *perms, int64_t n_cand, int64_t n_used, double total,
                          double *scores_out);
 
+/* ---- Part 2: search steps with the candidates enumerated on the device -------------------------
+ * The reference builds a Python index list and a gathered matrix per candidate (OG:344-365,
+ * 457-466, 519-538).  Here the scaffolds of a chromosome are contiguous ranges of the current
+ * selection ("layout"), the order/orientation under test is a list of (scaffold, reversed) pairs
+ * ("arrangement"), and a candidate is a couple of integers.
+ *
+ * hicmi_p2_layout: scaffold s occupies selection positions [scaf_start[s], scaf_start[s]+scaf_len[s]),
+ * bins in ascending-ID ('+') order.  Reset by hicmi_p2_select. */
+int hicmi_p2_layout(hicmi_ctx *ctx, const int32_t *scaf_start, const int32_t *scaf_len, int64_t n_scaf);
+/* The arrangement = scaffolds ids[0..S) left to right, rev[j] != 0 when scaffold j is laid down
+ * in '-' orientation (reorderScaffList, OG:310-321). */
+int hicmi_p2_set_arrangement(hicmi_ctx *ctx, const int32_t *ids, const uint8_t *rev, int64_t S);
+/* Literal total (see hicmi_p2_total) of the sub-matrix in the arrangement's order - what the
+ * reference computes from giveNewAdjMat's matrix at OG:343 / OG:448 / OG:506. */
+int hicmi_p2_arrangement_total(hicmi_ctx *ctx, double *total_out);
+/* Closed-form objective of the arrangement itself. */
+int hicmi_p2_arrangement_score(hicmi_ctx *ctx, double total, double *score_out);
+/* checkAllScores (OG:332-372): objective of the arrangement with scaffold new_id inserted at every
+ * gap g = 0..S in both orientations; scores_out[2*g + r], r = 1 for '-'.  2*(S+1) doubles. */
+int hicmi_p2_score_insertions(hicmi_ctx *ctx, int32_t new_id, double total, double *scores_out);
+/* Enumeration tables for windows of k scaffolds (permutations/removeReverseDuplicates/plusMinusPerms,
+ * OG:381-430): orders is n_orders x k (window-local scaffold index per slot), orients is
+ * n_orients x k (1 = '-').  Candidate c = order c / n_orients, orientation c % n_orients. */
+int hicmi_p2_window_tables(hicmi_ctx *ctx, int64_t k, const int8_t *orders, int64_t n_orders,
+                           const uint8_t *orients, int64_t n_orients);
+/* bruteForceBestScore / scanOrdering inner loops (OG:457-466, 519-538) for the window of k
+ * scaffolds starting at arrangement index `first`: delta_out[c] = (objective of candidate c) * total
+ * minus a term common to all candidates of this window (the pairs that lie outside it), so
+ * score(c) = score(c0) + (delta[c] - delta[c0]) / total for any candidate c0 whose score is known.
+ * n_orders * n_orients doubles. */
+int hicmi_p2_score_window(hicmi_ctx *ctx, int64_t first, int64_t k, double *delta_out);
+
 /* ---- timing ----------------------------------------------------------------------------------
  * Accumulated device time (HIP events on the context stream) per kernel family since the last
  * reset, for bench.py's roofline object.  names_out: caller buffer receiving ';'-separated names;

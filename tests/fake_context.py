@@ -79,3 +79,56 @@ class OracleContext:
         return out
 
     p2_score_exact = p2_score
+
+    # ---- device-side enumeration API, answered by expanding every candidate on the host
+    def p2_layout(self, scaf_start, scaf_len):
+        self.scaf_start = [int(v) for v in scaf_start]
+        self.scaf_len = [int(v) for v in scaf_len]
+
+    def _positions(self, sid, rev):
+        a = np.arange(self.scaf_start[sid], self.scaf_start[sid] + self.scaf_len[sid], dtype=np.int32)
+        return a[::-1] if rev else a
+
+    def p2_set_arrangement(self, ids, rev):
+        self.arr_ids = [int(v) for v in ids]
+        self.arr_rev = [int(v) for v in rev]
+        self._arr_len = len(self.arr_ids)
+
+    def _row(self, ids, rev):
+        return np.concatenate([self._positions(i, r) for i, r in zip(ids, rev)]) if len(ids) else np.zeros(0, np.int32)
+
+    def _literal(self, rows, total):
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        return self.p2_score(rows, total)
+
+    def p2_arrangement_total(self):
+        row = self._row(self.arr_ids, self.arr_rev)
+        return orc.lib().hio_total_upper(orc._dp(self.sub), self.sub.shape[1], orc._ip(row), len(row))
+
+    def p2_arrangement_score(self, total):
+        return float(self._literal(self._row(self.arr_ids, self.arr_rev)[None, :], total)[0])
+
+    def p2_score_insertions(self, new_id, total):
+        pieces = [self._positions(i, r) for i, r in zip(self.arr_ids, self.arr_rev)]
+        rows = []
+        for g in range(len(pieces) + 1):
+            for r in (0, 1):
+                rows.append(np.concatenate(pieces[:g] + [self._positions(int(new_id), r)] + pieces[g:]))
+        return self._literal(np.stack(rows), total)
+
+    def p2_window_tables(self, orders, orients):
+        self.orders = np.asarray(orders)
+        self.orients = np.asarray(orients)
+        self._n_window_cand = len(self.orders) * len(self.orients)
+
+    def p2_score_window(self, first, k):
+        head = self._row(self.arr_ids[:first], self.arr_rev[:first])
+        tail = self._row(self.arr_ids[first + k:], self.arr_rev[first + k:])
+        win = self.arr_ids[first:first + k]
+        rows = []
+        for o in self.orders:
+            for r in self.orients:
+                mid = [self._positions(win[int(j)], int(rv)) for j, rv in zip(o, r)]
+                rows.append(np.concatenate([head] + mid + [tail]))
+        # delta may contain any per-window constant; use "score * 1.0" (the caller divides by total again)
+        return self._literal(np.stack(rows), 1.0)

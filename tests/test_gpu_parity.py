@@ -253,6 +253,63 @@ def test_p2_literal_scores_bit_exact(hic, orc, n_used):
     assert np.allclose(fast, exact, rtol=1e-11, atol=0)
 
 
+def test_p2_device_enumeration_matches_explicit_candidates(hic, orc):
+    """Insertion and window candidates enumerated by the kernels (k_part2_search.hip) against the
+    same candidates spelled out as index lists and scored by hicmi_p2_score / the oracle."""
+    from hic_genome_assembler_amd import orderGenome as p2
+    rng = np.random.default_rng(17)
+    lens = [9, 1, 4, 12, 1, 7, 3, 5, 2]
+    n = sum(lens)
+    starts = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int32)
+    m = rng.random((n + 5, n + 5)); m = m + m.T
+    sel = rng.permutation(n + 5)[:n].astype(np.int32)
+
+    def pos(sid, rev):
+        a = np.arange(starts[sid], starts[sid] + lens[sid], dtype=np.int32)
+        return a[::-1] if rev else a
+    L = orc.lib()
+    sub = np.ascontiguousarray(m[np.ix_(sel, sel)])
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(m)
+        ctx.p2_select(sel)
+        ctx.p2_layout(starts, lens)
+        # --- arrangement of 7 scaffolds, total in arrangement order, arrangement score
+        ids = np.array([3, 0, 5, 8, 1, 6, 2], dtype=np.int32)
+        rev = np.array([0, 1, 1, 0, 0, 1, 0], dtype=np.uint8)
+        base = np.concatenate([pos(i, r) for i, r in zip(ids, rev)])
+        ctx.p2_set_arrangement(ids, rev)
+        total = ctx.p2_arrangement_total()
+        assert total == L.hio_total_upper(orc._dp(sub), n, orc._ip(base), len(base))
+        s_arr = ctx.p2_arrangement_score(total)
+        assert s_arr == pytest.approx(L.hio_cost_literal(orc._dp(sub), n, orc._ip(base), len(base), total), rel=1e-12)
+        # --- insertions of scaffold 4 and of scaffold 7
+        pieces = [pos(i, r) for i, r in zip(ids, rev)]
+        for new_id in (4, 7):
+            got = ctx.p2_score_insertions(new_id, total)
+            rows = [np.concatenate(pieces[:g] + [pos(new_id, r)] + pieces[g:]) for g in range(len(ids) + 1) for r in (0, 1)]
+            want = ctx.p2_score(np.stack(rows), total)
+            assert np.array_equal(got, want)          # same arithmetic, same reduction order
+        # --- windows of k = 3 and k = 5 scaffolds at every position, and the whole arrangement (k = S)
+        for k in (3, 5, 7):
+            orders, orients = p2._enumeration(k)
+            ctx.p2_window_tables(np.asarray(orders, np.int8),
+                                 np.asarray([[1 if sg == "-" else 0 for sg in r] for r in orients], np.uint8))
+            for first in range(0, len(ids) - k + 1):
+                delta = ctx.p2_score_window(first, k)
+                head = np.concatenate(pieces[:first]) if first else np.zeros(0, np.int32)
+                tail = np.concatenate(pieces[first + k:]) if first + k < len(ids) else np.zeros(0, np.int32)
+                rows = []
+                for o in orders:
+                    for r in orients:
+                        mid = [pos(int(ids[first + j]), sg == "-") for j, sg in zip(o, r)]
+                        rows.append(np.concatenate([head] + mid + [tail]))
+                want = ctx.p2_score(np.stack(rows), total)
+                c0 = p2._orient_index(k, ["-" if v else "+" for v in rev[first:first + k]])
+                assert np.array_equal(rows[c0], base)
+                got = s_arr + (delta - delta[c0]) / total
+                assert np.allclose(got, want, rtol=1e-12, atol=0)
+
+
 # --------------------------------------------------------------------------------- end to end
 def _run_product(name, tmp_path, record=None):
     from hic_genome_assembler_amd import scaffoldToChromosomes as p1, orderGenome as p2
@@ -264,19 +321,14 @@ def _run_product(name, tmp_path, record=None):
                    paths["hicProScaffSizeFile"], f("dendrogramOrder.txt"), f("a.png"), f("b.png"),
                    f("binGroups.txt"), f("assessment.txt"), f("chromosomeGroups.txt"),
                    True, False, spec["min_size"], 0.0, 20, spec["psig"], 5, .2, 100000)
-    orig = p2.SubMatrix.scores
     if record is not None:
-        def rec_scores(self, perms):
-            s = orig(self, perms)
-            record.extend(float(v) for v in s)
-            return s
-        p2.SubMatrix.scores = rec_scores
+        p2.SCORE_HOOK = lambda fast: record.extend(float(v) for v in fast)
     try:
         p2.runPipeline(paths["hicProBedFile"], paths["hicProBiasFile"], paths["hicProMatrixFile"],
                        f("chromosomeGroups.txt"), f("chromosomeOrders.txt"), out, "synthetic", f("g.png"),
                        "synthetic genome", f("plotOrder.txt"), spec["n_scaffolds"], spec["scan_scaffolds"], 100000)
     finally:
-        p2.SubMatrix.scores = orig
+        p2.SCORE_HOOK = None
     return out
 
 

@@ -31,19 +31,13 @@ def test_host_flow_reproduces_reference_files(fake_gpu, name, tmp_path):
                    f("binGroups.txt"), f("assessment.txt"), f("chromosomeGroups.txt"),
                    True, False, spec["min_size"], 0.0, 20, spec["psig"], 5, .2, 100000)
     scores = []
-    orig = p2.SubMatrix.scores
-
-    def rec(self, perms):
-        s = orig(self, perms)
-        scores.extend(float(v) for v in s)
-        return s
-    p2.SubMatrix.scores = rec
+    p2.SCORE_HOOK = lambda fast: scores.extend(float(v) for v in fast)
     try:
         p2.runPipeline(paths["hicProBedFile"], paths["hicProBiasFile"], paths["hicProMatrixFile"],
                        f("chromosomeGroups.txt"), f("chromosomeOrders.txt"), out, "synthetic", f("g.png"),
                        "synthetic genome", f("plotOrder.txt"), spec["n_scaffolds"], spec["scan_scaffolds"], 100000)
     finally:
-        p2.SubMatrix.scores = orig
+        p2.SCORE_HOOK = None
     for fn in gc.OUTPUT_FILES:
         with open(f(fn)) as fh:
             assert fh.read() == gc.golden_text(name, fn), fn
