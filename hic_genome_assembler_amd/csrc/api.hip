@@ -646,12 +646,13 @@ int hicmi_p2_score_exact(hicmi_ctx* c, const int32_t* perms, int64_t n_cand, int
     if (rc) return rc;
     rc = ensure(c->d_scores, c->scores_cap, n_cand);
     if (rc) return rc;
-    rc = ensure(c->d_T, c->t_cap, n_cand * n_used);
+    rc = ensure(c->d_T, c->t_cap, 2 * n_cand * n_used);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->d_perms, perms, sizeof(int32_t) * (size_t)(n_cand * n_used), hipMemcpyHostToDevice, c->stream));
     {
         Timed t(c, F_P2_EXACT, 8.0 * (double)n_cand * 0.5 * (double)n_used * (double)(n_used - 1));
-        launch_p2_score_exact(c->dM2, c->ld2, c->d_perms, (int)n_cand, (int)n_used, total, c->d_T, c->d_scores, c->stream);
+        launch_p2_score_exact(c->dM2, c->ld2, c->d_perms, (int)n_cand, (int)n_used, total, c->d_T,
+                              c->d_T + n_cand * n_used, c->d_scores, c->stream);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(scores_out, c->d_scores, sizeof(double) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
@@ -716,8 +717,7 @@ int hicmi_p2_set_arrangement(hicmi_ctx* c, const int32_t* ids, const uint8_t* re
     launch_arr_materialize(c->d_arr_id, c->d_arr_rev, c->d_arr_pos, (int)S, c->d_scaf_start, c->d_scaf_len, (int)c->n_arr,
                            c->d_pos2sel, c->stream);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));       // the host vectors above are reused by the next call
-    return HICMI_OK;
+    return HICMI_OK;                               // pageable H2D copies have consumed the host buffers on return
 }
 
 int hicmi_p2_arrangement_total(hicmi_ctx* c, double* total_out)
@@ -768,17 +768,29 @@ int hicmi_p2_score_insertions(hicmi_ctx* c, int32_t new_id, double total, double
     const int new_len = c->h_scaf_len[(size_t)new_id];
     if ((c->n_arr + new_len) * (int64_t)sizeof(int32_t) > 160 * 1024) return fail(HICMI_EUNSUPPORTED, "candidate longer than 40960 bins");
     HIPCHK(hipSetDevice(c->device));
-    int rc = ensure(c->d_scores, c->scores_cap, 2 * (S + 1));
+    // incremental form: BASE (64 partial sums) - STRADDLE(g) (prefix sums of S increments) + CROSS(g, r)
+    const int NB = 64;
+    const int64_t n_out = NB + S + 2 * (S + 1);
+    int rc = ensure(c->d_scores, c->scores_cap, n_out);
     if (rc) return rc;
     {
-        const double nn = (double)(c->n_arr + new_len);
-        Timed t(c, F_P2_INSERT, 8.0 * 2.0 * (double)(S + 1) * 0.5 * nn * (nn - 1.0));
-        launch_p2_score_insert(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, c->d_arr_pos, (int)S,
-                               c->h_scaf_start[(size_t)new_id], new_len, c->d_H, total, c->d_scores, c->stream);
+        const double nn = (double)c->n_arr;
+        Timed t(c, F_P2_INSERT, 8.0 * (0.5 * nn * (nn - 1.0) + nn * nn + 2.0 * (double)(S + 1) * (double)new_len * nn));
+        launch_p2_insert_delta(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, c->d_arr_pos, (int)S,
+                               c->h_scaf_start[(size_t)new_id], new_len, c->d_H, NB, c->d_scores, c->stream);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(scores_out, c->d_scores, sizeof(double) * (size_t)(2 * (S + 1)), hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> host((size_t)n_out);
+    HIPCHK(hipMemcpyAsync(host.data(), c->d_scores, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    double base = 0.0;
+    for (int b = 0; b < NB; b++) base += host[(size_t)b];
+    double straddle = 0.0;
+    for (int64_t g = 0; g <= S; g++) {
+        if (g > 0) straddle += host[(size_t)(NB + g - 1)];
+        for (int r = 0; r < 2; r++)
+            scores_out[2 * g + r] = (base - straddle + host[(size_t)(NB + S + 2 * g + r)]) / total;
+    }
     return HICMI_OK;
 }
 

@@ -31,7 +31,7 @@ void launch_similarity_row(const double* C, int64_t ldc, const int32_t* order, c
 void launch_p2_select(const double* C, int64_t ldc, const int32_t* sel, int n, double* M2, int64_t ld2, hipStream_t s);
 void launch_p2_total(const double* M2, int64_t ld2, int n, double* T, double* total, hipStream_t s);
 void launch_p2_score_exact(const double* M2, int64_t ld2, const int32_t* perms, int n_cand, int n_used, double total,
-                           double* T, double* scores, hipStream_t s);
+                           double* T, double* work, double* scores, hipStream_t s);
 void launch_p2_score(const double* M2, int64_t ld2, const int32_t* perms, int n_cand, int n_used, const double* H,
                      double inv_total_unused, double total, double* scores, hipStream_t s);
 
@@ -45,6 +45,8 @@ void launch_arr_materialize(const int32_t* arr_id, const uint8_t* arr_rev, const
 void launch_p2_score_insert(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const int32_t* arr_pos,
                             int S, int new_start, int new_len, const double* H, double total, double* scores,
                             hipStream_t s);
+void launch_p2_insert_delta(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const int32_t* arr_pos,
+                            int S, int new_start, int L, const double* H, int n_base_blocks, double* out, hipStream_t s);
 void launch_p2_score_arr(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const double* H,
                          double total, double* score, hipStream_t s);
 void launch_p2_window_G(const double* M2, int64_t ld2, const int32_t* pos2sel, int n, int p0, int m, const double* H,

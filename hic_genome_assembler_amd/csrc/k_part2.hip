@@ -41,78 +41,103 @@ __device__ __forceinline__ double wave_sum(double v)
 // two differently rounded totals, OG:506 vs OG:343), so the candidates that can win a step are
 // re-scored with exactly the reference's operation order:
 //   T_i   = numpy.trace(M_perm, offset=i): float64 add.reduce over the strided diagonal - pairwise
-//           blocks of <=128 with 8 partial sums, recursive halving, 8192-element chunks (OG:188)
+//           leaves of <=128 elements with 8 interleaved partial sums, recursive halving above that,
+//           8192-element chunks accumulated left to right (OG:188)
 //   total = Python sum of T_1..T_{n-1}, left to right                           (OG:343,448,506)
 //   cost  = sum_i ((T_1+..+T_i) / total) / i, left to right                      (OG:185-191)
-// One lane owns one diagonal (long and short diagonals interleaved for balance); the O(n) cum/cost
-// recurrence runs on one lane per candidate.
-struct DiagGather {
-    const double* __restrict__ M; int64_t ld; const int32_t* __restrict__ p; int off;
-    __device__ __forceinline__ double operator()(int t) const { return M[(int64_t)p[t] * ld + p[t + off]]; }
-};
+// The order of additions is fixed by NumPy, but most of them are independent: one 64-lane
+// workgroup owns one diagonal, 8 lanes own one leaf (lane k = partial sum k: at most 16 dependent
+// adds), the fixed ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) tree is three shuffles, and only the handful
+// of leaf results are combined serially along NumPy's recursion tree.
+static constexpr int MAX_LEAVES = 64;                  // an 8192-element chunk splits into <= 64 leaves
 
-__device__ __forceinline__ double pw_leaf_g(const DiagGather& g, int o, int n)
+// leaves of NumPy's pairwise recursion over [off, off+len), in order
+__device__ __forceinline__ int enumerate_leaves(int off, int len, int* leaf_off, int* leaf_len)
 {
-    if (n < 8) {
-        double r = 0.0;
-        for (int i = 0; i < n; i++) r += g(o + i);
-        return r;
+    int st_off[16], st_len[16], sp = 0, n = 0;
+    st_off[0] = off; st_len[0] = len; sp = 1;
+    while (sp > 0) {
+        sp--;
+        int o = st_off[sp], l = st_len[sp];
+        if (l <= 128) { leaf_off[n] = o; leaf_len[n] = l; n++; continue; }
+        int n2 = l / 2;
+        n2 -= n2 % 8;
+        st_off[sp] = o + n2; st_len[sp] = l - n2; sp++;          // right half (processed second)
+        st_off[sp] = o; st_len[sp] = n2; sp++;                    // left half
     }
-    double r0 = g(o), r1 = g(o + 1), r2 = g(o + 2), r3 = g(o + 3), r4 = g(o + 4), r5 = g(o + 5), r6 = g(o + 6),
-           r7 = g(o + 7);
-    int i, lim = n - (n % 8);
-    for (i = 8; i < lim; i += 8) {
-        r0 += g(o + i); r1 += g(o + i + 1); r2 += g(o + i + 2); r3 += g(o + i + 3);
-        r4 += g(o + i + 4); r5 += g(o + i + 5); r6 += g(o + i + 6); r7 += g(o + i + 7);
-    }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; i++) res += g(o + i);
-    return res;
+    return n;
 }
 
-__device__ double np_sum_g(const DiagGather& g, int n)
+// combine the leaf sums (in order) along the same recursion tree: left + right at every split
+__device__ __forceinline__ double combine_leaves(int len, const double* leaf_sum)
 {
-    struct Frame { int off, len, n2, stage; double left; };
-    double acc = 0.0;
-    for (int c = 0; c < n; c += 8192) {
-        int m = n - c < 8192 ? n - c : 8192;
-        Frame st[10];
-        int sp = 1;
-        double ret = 0.0;
-        st[0] = {c, m, 0, 0, 0.0};
-        while (sp > 0) {
-            Frame& f = st[sp - 1];
-            if (f.len <= 128) { ret = pw_leaf_g(g, f.off, f.len); sp--; continue; }
-            if (f.stage == 0) {
-                int n2 = f.len / 2;
-                n2 -= n2 % 8;
-                f.n2 = n2; f.stage = 1;
-                st[sp++] = {f.off, n2, 0, 0, 0.0};
-            } else if (f.stage == 1) {
-                f.left = ret; f.stage = 2;
-                st[sp++] = {f.off + f.n2, f.len - f.n2, 0, 0, 0.0};
-            } else { ret = f.left + ret; sp--; }
+    struct Frame { int len, n2, stage; double left; };
+    Frame st[10];
+    int sp = 1, next = 0;
+    double ret = 0.0;
+    st[0] = {len, 0, 0, 0.0};
+    while (sp > 0) {
+        Frame& f = st[sp - 1];
+        if (f.len <= 128) { ret = leaf_sum[next++]; sp--; continue; }
+        if (f.stage == 0) {
+            int n2 = f.len / 2;
+            n2 -= n2 % 8;
+            f.n2 = n2; f.stage = 1;
+            st[sp++] = {n2, 0, 0, 0.0};
+        } else if (f.stage == 1) {
+            f.left = ret; f.stage = 2;
+            st[sp++] = {f.len - f.n2, 0, 0, 0.0};
+        } else { ret = f.left + ret; sp--; }
+    }
+    return ret;
+}
+
+// T[cand][off] for off = 1..n_used-1 (T[cand][0] unused).  perms == nullptr: the identity order.
+__global__ __launch_bounds__(64) void k_p2_diag_sums(const double* __restrict__ M2, int64_t ld2,
+                                                     const int32_t* __restrict__ perms, int n_used,
+                                                     double* __restrict__ T)
+{
+    __shared__ int leaf_off[MAX_LEAVES], leaf_len[MAX_LEAVES];
+    __shared__ double leaf_sum[MAX_LEAVES];
+    __shared__ int s_nleaves;
+    const int cand = blockIdx.y, off = blockIdx.x + 1, lane = threadIdx.x, slot = lane >> 3, k = lane & 7;
+    const int32_t* __restrict__ p = perms ? perms + (int64_t)cand * n_used : nullptr;
+    const int len = n_used - off;
+    auto elem = [&](int t) -> double {
+        int a = p ? p[t] : t, b = p ? p[t + off] : t + off;
+        return M2[(int64_t)a * ld2 + b];
+    };
+    double acc = 0.0;                                   // chunk results accumulate left to right from 0.0
+    for (int c0 = 0; c0 < len; c0 += 8192) {
+        const int clen = len - c0 < 8192 ? len - c0 : 8192;
+        __syncthreads();
+        if (lane == 0) s_nleaves = enumerate_leaves(c0, clen, leaf_off, leaf_len);
+        __syncthreads();
+        const int nl = s_nleaves;
+        for (int l0 = 0; l0 < nl; l0 += 8) {
+            const int l = l0 + slot;
+            double r = 0.0;
+            int o = 0, n = 0, lim = 0;
+            if (l < nl) { o = leaf_off[l]; n = leaf_len[l]; lim = n - (n % 8); }
+            if (l < nl && n >= 8) {
+                r = elem(o + k);
+                for (int i = 8; i < lim; i += 8) r += elem(o + i + k);
+            }
+            // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)): every lane of the wave takes part in the shuffles
+            double s1 = r + __shfl_down(r, 1, 64);
+            double s2 = s1 + __shfl_down(s1, 2, 64);
+            double s3 = s2 + __shfl_down(s2, 4, 64);
+            if (l < nl && k == 0) {
+                double res;
+                if (n < 8) { res = 0.0; for (int i = 0; i < n; i++) res += elem(o + i); }
+                else { res = s3; for (int i = lim; i < n; i++) res += elem(o + i); }
+                leaf_sum[l] = res;
+            }
         }
-        acc += ret;
+        __syncthreads();
+        if (lane == 0) acc += combine_leaves(clen, leaf_sum);
     }
-    return acc;
-}
-
-// T[cand][i] for i = 1..n_used-1 (T[cand][0] unused).  perms == nullptr means the identity order.
-__global__ __launch_bounds__(256) void k_p2_diag_sums(const double* __restrict__ M2, int64_t ld2,
-                                                      const int32_t* __restrict__ perms, int n_used,
-                                                      double* __restrict__ T)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int32_t* p = reinterpret_cast<int32_t*>(smem);
-    const int cand = blockIdx.y;
-    for (int i = threadIdx.x; i < n_used; i += 256) p[i] = perms ? perms[(int64_t)cand * n_used + i] : i;
-    __syncthreads();
-    const int d = blockIdx.x * 256 + threadIdx.x;
-    if (d >= n_used - 1) return;
-    const int off = (d & 1) ? (n_used - 1 - (d >> 1)) : ((d >> 1) + 1);
-    DiagGather g{M2, ld2, p, off};
-    T[(int64_t)cand * n_used + off] = np_sum_g(g, n_used - off);
+    if (lane == 0) T[(int64_t)cand * n_used + off] = acc;
 }
 
 __global__ __launch_bounds__(64) void k_p2_total_exact(const double* __restrict__ T, int n_used, double* __restrict__ total)
@@ -123,47 +148,48 @@ __global__ __launch_bounds__(64) void k_p2_total_exact(const double* __restrict_
     total[0] = acc;
 }
 
-__global__ __launch_bounds__(64) void k_p2_cost_exact(const double* __restrict__ T, int n_cand, int n_used, double total,
-                                                      double* __restrict__ scores)
+// one workgroup per candidate: the running sum of T and the final sum of the quotients are serial
+// (lane 0), the two divisions per offset are done by all lanes in between.
+__global__ __launch_bounds__(256) void k_p2_cost_exact(const double* __restrict__ T, int n_used, double total,
+                                                       double* __restrict__ work, double* __restrict__ scores)
 {
-    int cand = blockIdx.x * 64 + threadIdx.x;
-    if (cand >= n_cand) return;
+    const int cand = blockIdx.x;
     const double* __restrict__ t = T + (int64_t)cand * n_used;
-    double cum = 0.0, cost = 0.0;
-    for (int i = 1; i < n_used; i++) {
-        cum += t[i];
-        cost += (cum / total / (double)i);
+    double* __restrict__ w = work + (int64_t)cand * n_used;
+    if (threadIdx.x == 0) {
+        double cum = 0.0;
+        for (int i = 1; i < n_used; i++) { cum += t[i]; w[i] = cum; }
     }
-    scores[cand] = cost;
+    __syncthreads();
+    for (int i = 1 + threadIdx.x; i < n_used; i += 256) w[i] = w[i] / total / (double)i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double cost = 0.0;
+        for (int i = 1; i < n_used; i++) cost += w[i];
+        scores[cand] = cost;
+    }
 }
 
 void launch_p2_total(const double* M2, int64_t ld2, int n, double* T, double* total, hipStream_t s)
 {
-    size_t lds = (((size_t)n * sizeof(int32_t)) + 15) & ~(size_t)15;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_diag_sums), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3((n - 1 + 255) / 256, 1), dim3(256), lds, s, M2, ld2,
-                                  (const int32_t*)nullptr, n, T);
+    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(n - 1, 1), dim3(64), 0, s, M2, ld2, (const int32_t*)nullptr, n, T);
     hipLaunchKernelGGL(k_p2_total_exact, dim3(1), dim3(64), 0, s, T, n, total);
 }
 
 void launch_p2_total_perm(const double* M2, int64_t ld2, const int32_t* d_perm, int n, double* T, double* total,
                           hipStream_t s)
 {
-    size_t lds = (((size_t)n * sizeof(int32_t)) + 15) & ~(size_t)15;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_diag_sums), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3((n - 1 + 255) / 256, 1), dim3(256), lds, s, M2, ld2, d_perm, n, T);
+    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(n - 1, 1), dim3(64), 0, s, M2, ld2, d_perm, n, T);
     hipLaunchKernelGGL(k_p2_total_exact, dim3(1), dim3(64), 0, s, T, n, total);
 }
 
+// T and work: n_cand x n_used doubles each
 void launch_p2_score_exact(const double* M2, int64_t ld2, const int32_t* perms, int n_cand, int n_used, double total,
-                           double* T, double* scores, hipStream_t s)
+                           double* T, double* work, double* scores, hipStream_t s)
 {
     if (n_cand <= 0) return;
-    size_t lds = (((size_t)n_used * sizeof(int32_t)) + 15) & ~(size_t)15;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_diag_sums), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (n_used > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3((n_used - 1 + 255) / 256, n_cand), dim3(256), lds, s, M2, ld2,
-                                       perms, n_used, T);
-    hipLaunchKernelGGL(k_p2_cost_exact, dim3((n_cand + 63) / 64), dim3(64), 0, s, T, n_cand, n_used, total, scores);
+    if (n_used > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(n_used - 1, n_cand), dim3(64), 0, s, M2, ld2, perms, n_used, T);
+    hipLaunchKernelGGL(k_p2_cost_exact, dim3(n_cand), dim3(256), 0, s, T, n_used, total, work, scores);
 }
 
 // One workgroup (4 waves) per candidate.  Wave w takes rows a = w, w+4, ... of the candidate's

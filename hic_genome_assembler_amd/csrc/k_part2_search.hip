@@ -108,6 +108,101 @@ void launch_p2_score_insert(const double* M2, int64_t ld2, const int32_t* pos2se
                        new_start, new_len, H, total, scores);
 }
 
+// ---- insertion, incremental form ------------------------------------------------------------------
+// Inserting a scaffold of L bins at gap g (position P = arr_pos[g]) shifts every bin at or after P by
+// L.  With n' = n_arr + L and w(d) = H[n'-1] - H[d-1]:
+//   score * total = BASE - STRADDLE(g) + CROSS(g, r)
+//   BASE        = sum_{a<b} M[a][b] w(b-a)                      arrangement pairs at their old distance
+//   STRADDLE(g) = sum_{a<P<=b} M[a][b] (w(b-a) - w(b-a+L))      pairs pushed apart by the insertion
+//   CROSS(g, r) = new-scaffold x arrangement pairs + pairs inside the new scaffold
+// STRADDLE(g+1) - STRADDLE(g) only involves the scaffold between the two gaps, so all gaps together
+// cost one pass over the sub-matrix instead of one pass per candidate.
+__device__ __forceinline__ double block_sum_256(double v, double* s_w)
+{
+    v = wave_sum_s(v);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__global__ __launch_bounds__(256) void k_p2_base_partial(const double* __restrict__ M2, int64_t ld2,
+                                                         const int32_t* __restrict__ pos2sel, int n_arr,
+                                                         const double* __restrict__ H, int n_tot,
+                                                         double* __restrict__ partial)
+{
+    __shared__ double s_w[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double hn = H[n_tot - 1];
+    double acc = 0.0;
+    for (int a = blockIdx.x * 4 + wave; a < n_arr - 1; a += gridDim.x * 4) {
+        const double* __restrict__ row = M2 + (int64_t)pos2sel[a] * ld2;
+        for (int b = a + 1 + lane; b < n_arr; b += 64) acc += row[pos2sel[b]] * (hn - H[b - a - 1]);
+    }
+    double sum = block_sum_256(acc, s_w);
+    if (threadIdx.x == 0) partial[blockIdx.x] = sum;
+}
+
+__global__ __launch_bounds__(256) void k_p2_insert_straddle(const double* __restrict__ M2, int64_t ld2,
+                                                            const int32_t* __restrict__ pos2sel, int n_arr,
+                                                            const int32_t* __restrict__ arr_pos, int L,
+                                                            const double* __restrict__ H, double* __restrict__ D)
+{
+    __shared__ double s_w[4];
+    const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int P0 = arr_pos[g], P1 = arr_pos[g + 1];
+    double acc = 0.0;
+    for (int u = P0 + wave; u < P1; u += 4) {             // bins of the scaffold between gap g and g+1
+        const double* __restrict__ row = M2 + (int64_t)pos2sel[u] * ld2;
+        for (int a = lane; a < P0; a += 64) {               // pairs (a, u) stop straddling
+            int d = u - a;
+            acc -= row[pos2sel[a]] * (H[d + L - 1] - H[d - 1]);
+        }
+        for (int b = P1 + lane; b < n_arr; b += 64) {       // pairs (u, b) start straddling
+            int d = b - u;
+            acc += row[pos2sel[b]] * (H[d + L - 1] - H[d - 1]);
+        }
+    }
+    double sum = block_sum_256(acc, s_w);
+    if (threadIdx.x == 0) D[g] = sum;
+}
+
+__global__ __launch_bounds__(256) void k_p2_insert_cross(const double* __restrict__ M2, int64_t ld2,
+                                                         const int32_t* __restrict__ pos2sel, int n_arr,
+                                                         const int32_t* __restrict__ arr_pos, int new_start, int L,
+                                                         const double* __restrict__ H, double* __restrict__ cross)
+{
+    __shared__ double s_w[4];
+    const int g = blockIdx.x >> 1, r = blockIdx.x & 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int P = arr_pos[g];
+    const double hn = H[n_arr + L - 1];
+    double acc = 0.0;
+    for (int e = wave; e < L; e += 4) {
+        const int xe = new_start + (r ? L - 1 - e : e);
+        const double* __restrict__ row = M2 + (int64_t)xe * ld2;
+        for (int q = lane; q < n_arr; q += 64) {
+            int d = q < P ? (P + e - q) : (q + L - (P + e));
+            acc += row[pos2sel[q]] * (hn - H[d - 1]);
+        }
+        for (int e2 = e + 1 + lane; e2 < L; e2 += 64) {
+            int x2 = new_start + (r ? L - 1 - e2 : e2);
+            acc += row[x2] * (hn - H[e2 - e - 1]);
+        }
+    }
+    double sum = block_sum_256(acc, s_w);
+    if (threadIdx.x == 0) cross[blockIdx.x] = sum;
+}
+
+void launch_p2_insert_delta(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const int32_t* arr_pos,
+                            int S, int new_start, int L, const double* H, int n_base_blocks, double* out, hipStream_t s)
+{
+    // out: [n_base_blocks partial sums of BASE][S straddle increments][2(S+1) cross terms]
+    hipLaunchKernelGGL(k_p2_base_partial, dim3(n_base_blocks), dim3(256), 0, s, M2, ld2, pos2sel, n_arr, H, n_arr + L, out);
+    hipLaunchKernelGGL(k_p2_insert_straddle, dim3(S), dim3(256), 0, s, M2, ld2, pos2sel, n_arr, arr_pos, L, H,
+                       out + n_base_blocks);
+    hipLaunchKernelGGL(k_p2_insert_cross, dim3(2 * (S + 1)), dim3(256), 0, s, M2, ld2, pos2sel, n_arr, arr_pos, new_start,
+                       L, H, out + n_base_blocks + S);
+}
+
 // score of the arrangement itself (one candidate): perm = pos2sel
 __global__ __launch_bounds__(256) void k_p2_score_arr(const double* __restrict__ M2, int64_t ld2,
                                                       const int32_t* __restrict__ pos2sel, int n_arr,
