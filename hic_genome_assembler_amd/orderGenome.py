@@ -70,6 +70,7 @@ class ChromosomeLayout:
         self.ctx.p2_select(sel)
         self.ctx.p2_layout(self.start, self.length)
         self._tables_k = None
+        self._pos_cache = {}
 
     def covers(self, scaffs):
         return all(s.name in self.sid for s in scaffs)
@@ -81,9 +82,13 @@ class ChromosomeLayout:
         return ids, rev
 
     def positions(self, sid, rev):
-        """Selection indices of one scaffold laid down forward / reversed."""
-        a = np.arange(self.start[sid], self.start[sid] + self.length[sid], dtype=np.int32)
-        return a[::-1] if rev else a
+        """Selection indices of one scaffold laid down forward / reversed (cached)."""
+        key = (sid, bool(rev))
+        hit = self._pos_cache.get(key)
+        if hit is None:
+            a = np.arange(self.start[sid], self.start[sid] + self.length[sid], dtype=np.int32)
+            hit = self._pos_cache[key] = np.ascontiguousarray(a[::-1]) if rev else a
+        return hit
 
     def node_row(self, ids, rev):
         return np.concatenate([self.positions(int(i), int(r)) for i, r in zip(ids, rev)]) if len(ids) else \
@@ -252,8 +257,38 @@ def giveNewAdjMat(matrix: GenomeMatrix, scaffList, binList):
     selects just these scaffolds."""
     if matrix.chrom is None or not matrix.chrom.covers(scaffList):
         matrix.chrom = ChromosomeLayout(matrix, scaffList, binList)
-    orderDict = {b: i for i, b in enumerate(n for s in scaffList for n in s.binList)}
-    return SubMatrix(matrix.chrom, scaffList), orderDict
+    return SubMatrix(matrix.chrom, scaffList), _OrderDict(scaffList)
+
+
+class _OrderDict(dict):
+    """{binID: index in the sub-matrix} of giveNewAdjMat (OG:302), filled on first use: the device
+    path never needs it, only callers of the reference's function-level API do."""
+
+    def __init__(self, scaffList):
+        super().__init__()
+        self._nodes = [n for s in scaffList for n in s.binList]
+        self._filled = False
+
+    def _fill(self):
+        if not self._filled:
+            self._filled = True
+            self.update((b, i) for i, b in enumerate(self._nodes))
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def __len__(self):
+        self._fill()
+        return dict.__len__(self)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __contains__(self, k):
+        self._fill()
+        return dict.__contains__(self, k)
 
 
 def reorderScaffList(orderList, orientationList, scaffDict):
@@ -362,14 +397,16 @@ def _window_scores(view: SubMatrix, arrangement, first, k, known_fast=None):
         base = ctx.p2_arrangement_score(total) if known_fast is None else known_fast
         fast = base + (delta - delta[c0]) / total
     n_ori = len(orients)
-    head = layout.node_row(ids[:first], rev[:first])
-    tail = layout.node_row(ids[first + k:], rev[first + k:])
     win = ids[first:first + k]
+    ends = []
 
     def row_of(c):
+        if not ends:                                      # built only if a candidate gets short-listed
+            ends.append(layout.node_row(ids[:first], rev[:first]))
+            ends.append(layout.node_row(ids[first + k:], rev[first + k:]))
         o, r = orders[c // n_ori], orients[c % n_ori]
         mid = [layout.positions(int(win[j]), sg == "-") for j, sg in zip(o, r)]
-        return np.concatenate([head] + mid + [tail])
+        return np.concatenate([ends[0]] + mid + [ends[1]])
     return fast, row_of
 
 
