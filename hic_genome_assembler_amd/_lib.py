@@ -201,6 +201,7 @@ class Context:
     def p2_select(self, sel):
         sel = np.ascontiguousarray(sel, dtype=np.int32)
         _check(self._lib.hicmi_p2_select(self._h, _ptr(sel), len(sel)))
+        self._arr_sig = None
 
     def p2_total(self) -> float:
         t = c_dbl()
@@ -231,12 +232,17 @@ class Context:
         a = np.ascontiguousarray(scaf_start, dtype=np.int32)
         b = np.ascontiguousarray(scaf_len, dtype=np.int32)
         _check(self._lib.hicmi_p2_layout(self._h, _ptr(a), _ptr(b), len(a)))
+        self._arr_sig = None
 
     def p2_set_arrangement(self, ids, rev):
         a = np.ascontiguousarray(ids, dtype=np.int32)
         b = np.ascontiguousarray(rev, dtype=np.uint8)
+        sig = a.tobytes() + b.tobytes()
+        if sig == getattr(self, "_arr_sig", None):
+            return                                   # the device already holds this arrangement
         _check(self._lib.hicmi_p2_set_arrangement(self._h, _ptr(a), _ptr(b), len(a)))
         self._arr_len = len(a)
+        self._arr_sig = sig
 
     def p2_arrangement_total(self) -> float:
         t = c_dbl()

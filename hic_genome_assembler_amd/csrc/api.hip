@@ -79,14 +79,15 @@ struct hicmi_ctx {
     // part 2 search state: layout (scaffold ranges of the selection), arrangement, window tables
     int32_t *d_scaf_start = nullptr, *d_scaf_len = nullptr; int64_t scaf_cap = 0, n_scaf = 0;
     std::vector<int32_t> h_scaf_start, h_scaf_len;
-    int32_t *d_arr_id = nullptr, *d_arr_pos = nullptr; uint8_t* d_arr_rev = nullptr; int64_t arr_cap = 0;
+    int32_t* d_arr_packed = nullptr; int64_t arr_cap = 0;       // [S ids][S+1 positions][S reversed flags]
+    std::vector<int32_t> h_arr_packed;
     std::vector<int32_t> h_arr_id, h_arr_pos; std::vector<uint8_t> h_arr_rev;
     int32_t* d_pos2sel = nullptr; int64_t pos_cap = 0; int64_t n_arr = 0;
     int8_t* d_orders = nullptr; uint8_t* d_orients = nullptr; int64_t ord_cap = 0, ori_cap = 0;
     int tab_k = 0; int64_t n_orders = 0, n_orients = 0;
     double* d_G = nullptr; int64_t g_cap = 0;
     double* d_delta = nullptr; int64_t delta_cap = 0;
-    int32_t *d_win_id = nullptr, *d_win_off = nullptr; uint8_t* d_win_rev = nullptr;
+
     // timing
     bool timing = false;
     std::vector<TimedRegion> regions;
@@ -218,9 +219,9 @@ int hicmi_destroy(hicmi_ctx* c)
     free_dev(c->d_x); free_dev(c->d_sig); free_dev(c->d_tmp);
     free_dev(c->dM2); free_dev(c->d_sel); free_dev(c->d_H); free_dev(c->d_perms); free_dev(c->d_scores);
     free_dev(c->d_partial); free_dev(c->d_T);
-    free_dev(c->d_scaf_start); free_dev(c->d_scaf_len); free_dev(c->d_arr_id); free_dev(c->d_arr_pos);
-    free_dev(c->d_arr_rev); free_dev(c->d_pos2sel); free_dev(c->d_orders); free_dev(c->d_orients);
-    free_dev(c->d_G); free_dev(c->d_delta); free_dev(c->d_win_id); free_dev(c->d_win_off); free_dev(c->d_win_rev);
+    free_dev(c->d_scaf_start); free_dev(c->d_scaf_len); free_dev(c->d_arr_packed);
+    free_dev(c->d_pos2sel); free_dev(c->d_orders); free_dev(c->d_orients);
+    free_dev(c->d_G); free_dev(c->d_delta);
     for (auto& r : c->regions) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
@@ -706,26 +707,19 @@ int hicmi_p2_set_arrangement(hicmi_ctx* c, const int32_t* ids, const uint8_t* re
         pos[(size_t)j + 1] = pos[(size_t)j] + c->h_scaf_len[(size_t)ids[j]];
     }
     HIPCHK(hipSetDevice(c->device));
-    if (c->arr_cap < S + 1) {
-        free_dev(c->d_arr_id); free_dev(c->d_arr_pos); free_dev(c->d_arr_rev);
-        c->d_arr_id = c->d_arr_pos = nullptr; c->d_arr_rev = nullptr; c->arr_cap = 0;
-        int64_t cap = std::max<int64_t>(S + 1, c->n_scaf + 1);
-        HIPCHK(hipMalloc((void**)&c->d_arr_id, sizeof(int32_t) * (size_t)cap));
-        HIPCHK(hipMalloc((void**)&c->d_arr_pos, sizeof(int32_t) * (size_t)cap));
-        HIPCHK(hipMalloc((void**)&c->d_arr_rev, (size_t)cap));
-        c->arr_cap = cap;
-    }
-    int rc = ensure(c->d_pos2sel, c->pos_cap, c->n2);
+    int rc = ensure(c->d_arr_packed, c->arr_cap, 3 * std::max<int64_t>(S, c->n_scaf) + 2);
+    if (rc) return rc;
+    rc = ensure(c->d_pos2sel, c->pos_cap, c->n2);
     if (rc) return rc;
     c->h_arr_id.assign(ids, ids + S); c->h_arr_rev.assign(rev, rev + S); c->h_arr_pos = pos;
     c->n_arr = pos[(size_t)S];
-    HIPCHK(hipMemcpyAsync(c->d_arr_id, ids, sizeof(int32_t) * (size_t)S, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_arr_rev, rev, (size_t)S, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_arr_pos, pos.data(), sizeof(int32_t) * (size_t)(S + 1), hipMemcpyHostToDevice, c->stream));
-    launch_arr_materialize(c->d_arr_id, c->d_arr_rev, c->d_arr_pos, (int)S, c->d_scaf_start, c->d_scaf_len, (int)c->n_arr,
-                           c->d_pos2sel, c->stream);
+    c->h_arr_packed.resize((size_t)(3 * S + 1));
+    for (int64_t j = 0; j < S; j++) { c->h_arr_packed[(size_t)j] = ids[j]; c->h_arr_packed[(size_t)(2 * S + 1 + j)] = rev[j] ? 1 : 0; }
+    for (int64_t j = 0; j <= S; j++) c->h_arr_packed[(size_t)(S + j)] = pos[(size_t)j];
+    HIPCHK(hipMemcpyAsync(c->d_arr_packed, c->h_arr_packed.data(), sizeof(int32_t) * (size_t)(3 * S + 1), hipMemcpyHostToDevice, c->stream));
+    launch_arr_materialize(c->d_arr_packed, (int)S, c->d_scaf_start, c->d_scaf_len, (int)c->n_arr, c->d_pos2sel, c->stream);
     HIPCHK(hipGetLastError());
-    return HICMI_OK;                               // pageable H2D copies have consumed the host buffers on return
+    return HICMI_OK;
 }
 
 int hicmi_p2_arrangement_total(hicmi_ctx* c, double* total_out)
@@ -753,15 +747,20 @@ int hicmi_p2_arrangement_score(hicmi_ctx* c, double total, double* score_out)
     if (c->n_arr < 1) return fail(HICMI_EINVAL, "hicmi_p2_set_arrangement has not run");
     if (c->n_arr < 2) { *score_out = 0.0; return HICMI_OK; }
     HIPCHK(hipSetDevice(c->device));
-    int rc = ensure(c->d_scores, c->scores_cap, 1);
+    const int NB = 64;
+    int rc = ensure(c->d_scores, c->scores_cap, NB);
     if (rc) return rc;
     {
         Timed t(c, F_P2_SCORE, 4.0 * (double)c->n_arr * (double)(c->n_arr - 1));
-        launch_p2_score_arr(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, c->d_H, total, c->d_scores, c->stream);
+        launch_p2_base_partial(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, c->d_H, (int)c->n_arr, NB, c->d_scores, c->stream);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(score_out, c->d_scores, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    double part[NB];
+    HIPCHK(hipMemcpyAsync(part, c->d_scores, sizeof(double) * NB, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    double sum = 0.0;
+    for (int b = 0; b < NB; b++) sum += part[b];
+    *score_out = sum / total;
     return HICMI_OK;
 }
 
@@ -784,7 +783,7 @@ int hicmi_p2_score_insertions(hicmi_ctx* c, int32_t new_id, double total, double
     {
         const double nn = (double)c->n_arr;
         Timed t(c, F_P2_INSERT, 8.0 * (0.5 * nn * (nn - 1.0) + nn * nn + 2.0 * (double)(S + 1) * (double)new_len * nn));
-        launch_p2_insert_delta(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, c->d_arr_pos, (int)S,
+        launch_p2_insert_delta(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, c->d_arr_packed + S, (int)S,
                                c->h_scaf_start[(size_t)new_id], new_len, c->d_H, NB, c->d_scores, c->stream);
     }
     HIPCHK(hipGetLastError());
@@ -833,21 +832,15 @@ int hicmi_p2_score_window(hicmi_ctx* c, int64_t first, int64_t k, double* delta_
     if (rc) return rc;
     rc = ensure(c->d_delta, c->delta_cap, n_cand);
     if (rc) return rc;
-    if (!c->d_win_id) {
-        HIPCHK(hipMalloc((void**)&c->d_win_id, sizeof(int32_t) * 8));
-        HIPCHK(hipMalloc((void**)&c->d_win_off, sizeof(int32_t) * 8));
-        HIPCHK(hipMalloc((void**)&c->d_win_rev, 8));
-    }
-    int32_t win_id[8], win_off[8]; uint8_t win_rev[8];
+    WindowDesc wd;
+    memset(&wd, 0, sizeof(wd));
     for (int64_t j = 0; j < k; j++) {
-        win_id[j] = c->h_arr_id[(size_t)(first + j)];
-        win_rev[j] = c->h_arr_rev[(size_t)(first + j)];
-        win_off[j] = c->h_arr_pos[(size_t)(first + j)] - p0;
+        const int32_t sc = c->h_arr_id[(size_t)(first + j)];
+        wd.start[j] = c->h_scaf_start[(size_t)sc];
+        wd.len[j] = c->h_scaf_len[(size_t)sc];
+        wd.off[j] = c->h_arr_pos[(size_t)(first + j)] - p0;
+        wd.rev[j] = c->h_arr_rev[(size_t)(first + j)];
     }
-    HIPCHK(hipMemcpyAsync(c->d_win_id, win_id, sizeof(int32_t) * (size_t)k, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_win_off, win_off, sizeof(int32_t) * (size_t)k, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_win_rev, win_rev, (size_t)k, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));       // stack arrays above
     {
         Timed t(c, F_P2_WINDOW_G, 8.0 * (double)m * (double)(c->n_arr - m));
         launch_p2_window_G(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, p0, m, c->d_H, c->d_G, c->stream);
@@ -855,8 +848,7 @@ int hicmi_p2_score_window(hicmi_ctx* c, int64_t first, int64_t k, double* delta_
     HIPCHK(hipGetLastError());
     {
         Timed t(c, F_P2_WINDOW_DELTA, 8.0 * (double)n_cand * (0.5 * (double)m * (double)(m - 1) + (double)m));
-        launch_p2_window_delta(c->dM2, c->ld2, (int)c->n_arr, m, (int)k, c->d_win_id, c->d_win_rev, c->d_win_off,
-                               c->d_scaf_start, c->d_scaf_len, c->d_orders, c->d_orients, (int)c->n_orders,
+        launch_p2_window_delta(c->dM2, c->ld2, (int)c->n_arr, m, (int)k, wd, c->d_orders, c->d_orients, (int)c->n_orders,
                                (int)c->n_orients, c->d_H, c->d_G, c->d_delta, c->stream);
     }
     HIPCHK(hipGetLastError());

@@ -40,21 +40,22 @@ void launch_p2_total_perm(const double* M2, int64_t ld2, const int32_t* d_perm, 
                           hipStream_t s);
 
 // k_part2_search.hip
-void launch_arr_materialize(const int32_t* arr_id, const uint8_t* arr_rev, const int32_t* arr_pos, int S,
-                            const int32_t* scaf_start, const int32_t* scaf_len, int n_arr, int32_t* pos2sel,
-                            hipStream_t s);
-void launch_p2_score_insert(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const int32_t* arr_pos,
-                            int S, int new_start, int new_len, const double* H, double total, double* scores,
-                            hipStream_t s);
+struct WindowDesc {            // the k <= 8 scaffolds of a window, passed to the kernel by value
+    int32_t start[8];          // selection range start of window scaffold j
+    int32_t len[8];
+    int32_t off[8];            // offset of scaffold j inside the window in the CURRENT arrangement
+    uint8_t rev[8];            // current orientation of scaffold j
+};
+void launch_arr_materialize(const int32_t* packed, int S, const int32_t* scaf_start, const int32_t* scaf_len, int n_arr,
+                            int32_t* pos2sel, hipStream_t s);
+void launch_p2_base_partial(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const double* H, int n_tot,
+                            int n_blocks, double* out, hipStream_t s);
 void launch_p2_insert_delta(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const int32_t* arr_pos,
                             int S, int new_start, int L, const double* H, int n_base_blocks, double* out, hipStream_t s);
-void launch_p2_score_arr(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const double* H,
-                         double total, double* score, hipStream_t s);
 void launch_p2_window_G(const double* M2, int64_t ld2, const int32_t* pos2sel, int n, int p0, int m, const double* H,
                         double* G, hipStream_t s);
-void launch_p2_window_delta(const double* M2, int64_t ld2, int n, int m, int k, const int32_t* win_id,
-                            const uint8_t* win_rev, const int32_t* win_off, const int32_t* scaf_start,
-                            const int32_t* scaf_len, const int8_t* orders, const uint8_t* orients, int n_ord, int n_ori,
-                            const double* H, const double* G, double* delta, hipStream_t s);
+void launch_p2_window_delta(const double* M2, int64_t ld2, int n, int m, int k, const WindowDesc& w, const int8_t* orders,
+                            const uint8_t* orients, int n_ord, int n_ori, const double* H, const double* G,
+                            double* delta, hipStream_t s);
 
 }  // namespace hicmi

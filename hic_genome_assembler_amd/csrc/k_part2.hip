@@ -140,11 +140,27 @@ __global__ __launch_bounds__(64) void k_p2_diag_sums(const double* __restrict__ 
     if (lane == 0) T[(int64_t)cand * n_used + off] = acc;
 }
 
-__global__ __launch_bounds__(64) void k_p2_total_exact(const double* __restrict__ T, int n_used, double* __restrict__ total)
+// The serial parts below are chains of dependent fp64 adds (the reference's order cannot be
+// re-associated); everything around them is staged through LDS so the chain never waits on memory.
+static constexpr int SERIAL_LDS_MAX = 8192;             // doubles staged in LDS (64 KB); longer inputs stream from L2
+
+__global__ __launch_bounds__(256) void k_p2_total_exact(const double* __restrict__ T, int n_used, double* __restrict__ total)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
+    double* t = reinterpret_cast<double*>(smem_t);
+    const bool staged = n_used <= SERIAL_LDS_MAX;
+    if (staged) {
+        for (int i = threadIdx.x; i < n_used; i += 256) t[i] = T[i];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
     double acc = 0.0;                                   // Python sum(): 0 + T_1 + T_2 + ...
-    for (int i = 1; i < n_used; i++) acc += T[i];
+    if (staged) {
+#pragma unroll 8
+        for (int i = 1; i < n_used; i++) acc += t[i];
+    } else {
+        for (int i = 1; i < n_used; i++) acc += T[i];
+    }
     total[0] = acc;
 }
 
@@ -153,34 +169,50 @@ __global__ __launch_bounds__(64) void k_p2_total_exact(const double* __restrict_
 __global__ __launch_bounds__(256) void k_p2_cost_exact(const double* __restrict__ T, int n_used, double total,
                                                        double* __restrict__ work, double* __restrict__ scores)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
     const int cand = blockIdx.x;
-    const double* __restrict__ t = T + (int64_t)cand * n_used;
-    double* __restrict__ w = work + (int64_t)cand * n_used;
+    const double* __restrict__ tg = T + (int64_t)cand * n_used;
+    const bool staged = n_used <= SERIAL_LDS_MAX;
+    double* w = staged ? reinterpret_cast<double*>(smem_c) : work + (int64_t)cand * n_used;
+    if (staged) {
+        for (int i = threadIdx.x; i < n_used; i += 256) w[i] = tg[i];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         double cum = 0.0;
-        for (int i = 1; i < n_used; i++) { cum += t[i]; w[i] = cum; }
+        if (staged) {
+#pragma unroll 8
+            for (int i = 1; i < n_used; i++) { cum += w[i]; w[i] = cum; }
+        } else {
+            for (int i = 1; i < n_used; i++) { cum += tg[i]; w[i] = cum; }
+        }
     }
     __syncthreads();
     for (int i = 1 + threadIdx.x; i < n_used; i += 256) w[i] = w[i] / total / (double)i;
     __syncthreads();
     if (threadIdx.x == 0) {
         double cost = 0.0;
+#pragma unroll 8
         for (int i = 1; i < n_used; i++) cost += w[i];
         scores[cand] = cost;
     }
 }
 
+static size_t serial_lds_bytes(int n) { return n <= SERIAL_LDS_MAX ? (((size_t)n * sizeof(double)) + 15) & ~(size_t)15 : 16; }
+
 void launch_p2_total(const double* M2, int64_t ld2, int n, double* T, double* total, hipStream_t s)
 {
     if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(n - 1, 1), dim3(64), 0, s, M2, ld2, (const int32_t*)nullptr, n, T);
-    hipLaunchKernelGGL(k_p2_total_exact, dim3(1), dim3(64), 0, s, T, n, total);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_total_exact), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipLaunchKernelGGL(k_p2_total_exact, dim3(1), dim3(256), serial_lds_bytes(n), s, T, n, total);
 }
 
 void launch_p2_total_perm(const double* M2, int64_t ld2, const int32_t* d_perm, int n, double* T, double* total,
                           hipStream_t s)
 {
     if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(n - 1, 1), dim3(64), 0, s, M2, ld2, d_perm, n, T);
-    hipLaunchKernelGGL(k_p2_total_exact, dim3(1), dim3(64), 0, s, T, n, total);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_total_exact), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipLaunchKernelGGL(k_p2_total_exact, dim3(1), dim3(256), serial_lds_bytes(n), s, T, n, total);
 }
 
 // T and work: n_cand x n_used doubles each
@@ -189,7 +221,8 @@ void launch_p2_score_exact(const double* M2, int64_t ld2, const int32_t* perms, 
 {
     if (n_cand <= 0) return;
     if (n_used > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(n_used - 1, n_cand), dim3(64), 0, s, M2, ld2, perms, n_used, T);
-    hipLaunchKernelGGL(k_p2_cost_exact, dim3(n_cand), dim3(256), 0, s, T, n_used, total, work, scores);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_cost_exact), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipLaunchKernelGGL(k_p2_cost_exact, dim3(n_cand), dim3(256), serial_lds_bytes(n_used), s, T, n_used, total, work, scores);
 }
 
 // One workgroup (4 waves) per candidate.  Wave w takes rows a = w, w+4, ... of the candidate's

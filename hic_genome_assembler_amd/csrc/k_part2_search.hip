@@ -6,17 +6,20 @@
 // contiguous ranges of that selection (the "layout"); the current order/orientation is a short
 // list of (scaffold, reversed) pairs (the "arrangement") expanded on the device into
 // pos2sel[position] -> selection index.  Candidates are then described by a few integers:
-//   insertion : (gap, reversed) of one new scaffold          -> 2(S+1) candidates, scored directly
+//   insertion : (gap, reversed) of one new scaffold          -> 2(S+1) candidates
 //   window    : (order index, orientation index) into the enumeration tables of k scaffolds
-//               -> k!/2 * 2^k candidates, scored INCREMENTALLY:
-//       score(c) * total = [pairs outside the window]                      same for every c
-//                        + sum_t G[x_t][t]                                  window bin x_t at slot t
-//                        + sum_{s<t} M[u_s][u_t] * w(t-s)                   pairs inside the window
-//       with G[x][t] = sum_{q outside} M[u_x][bin at q] * w(|p0+t-q|),  w(d) = H[n-1] - H[d-1].
-//     G is an (m x m) table per window (m = bins in the window): m*m*(n-m) multiply-adds instead
-//     of (#candidates * n^2/2).  Only differences between candidates of one window are used by the
-//     host, and the winners are re-scored literally (k_p2_diag_sums), so rounding of this
-//     decomposition never reaches an output.
+//               -> k!/2 * 2^k candidates
+// and both are scored INCREMENTALLY (closed form, fp64; w(d) = H[n-1] - H[d-1]):
+//   window:    score(c) * total = [pairs outside the window]                      same for every c
+//                               + sum_t G[x_t][t]                                  window bin x_t at slot t
+//                               + sum_{s<t} M[u_s][u_t] * w(t-s)                   pairs inside the window
+//              G[x][t] = sum_{q outside} M[u_x][bin at q] * w(|p0+t-q|): an (m x m) table per window
+//              (m = bins in the window): m*m*(n-m) multiply-adds instead of (#candidates * n^2/2).
+//   insertion: score * total = BASE - STRADDLE(g) + CROSS(g, r)   (see below)
+// Only differences between candidates of one step are used by the host, and the winners are
+// re-scored literally (k_p2_diag_sums), so the rounding of these decompositions never reaches an
+// output.  Every kernel first copies pos2sel into LDS: the matrix is then reached through ONE level
+// of indirection, and consecutive positions inside a scaffold are consecutive addresses.
 #include "hicmi_internal.h"
 
 namespace hicmi {
@@ -28,14 +31,26 @@ __device__ __forceinline__ double wave_sum_s(double v)
     return v;
 }
 
-// pos2sel[q] for the arrangement (arr_id, arr_rev) with prefix positions arr_pos[0..S]
-__global__ __launch_bounds__(256) void k_arr_materialize(const int32_t* __restrict__ arr_id,
-                                                         const uint8_t* __restrict__ arr_rev,
-                                                         const int32_t* __restrict__ arr_pos, int S,
+__device__ __forceinline__ double block_sum_256(double v, double* s_w)
+{
+    v = wave_sum_s(v);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+static size_t perm_lds_bytes(int n) { return (((size_t)n * sizeof(int32_t)) + 15) & ~(size_t)15; }
+
+// pos2sel[q] for the arrangement (arr_id, arr_rev) with prefix positions arr_pos[0..S]; the three
+// arrays arrive packed in one buffer: [S ids][S+1 positions][S reversed flags as int32]
+__global__ __launch_bounds__(256) void k_arr_materialize(const int32_t* __restrict__ packed, int S,
                                                          const int32_t* __restrict__ scaf_start,
                                                          const int32_t* __restrict__ scaf_len, int n_arr,
                                                          int32_t* __restrict__ pos2sel)
 {
+    const int32_t* __restrict__ arr_id = packed;
+    const int32_t* __restrict__ arr_pos = packed + S;
+    const int32_t* __restrict__ arr_rev = packed + 2 * S + 1;
     int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= n_arr) return;
     int lo = 0, hi = S;                                   // largest j with arr_pos[j] <= q
@@ -47,65 +62,44 @@ __global__ __launch_bounds__(256) void k_arr_materialize(const int32_t* __restri
     pos2sel[q] = scaf_start[sc] + (arr_rev[lo] ? len - 1 - off : off);
 }
 
-void launch_arr_materialize(const int32_t* arr_id, const uint8_t* arr_rev, const int32_t* arr_pos, int S,
-                            const int32_t* scaf_start, const int32_t* scaf_len, int n_arr, int32_t* pos2sel,
-                            hipStream_t s)
+void launch_arr_materialize(const int32_t* packed, int S, const int32_t* scaf_start, const int32_t* scaf_len, int n_arr,
+                            int32_t* pos2sel, hipStream_t s)
 {
     if (n_arr <= 0) return;
-    hipLaunchKernelGGL(k_arr_materialize, dim3((n_arr + 255) / 256), dim3(256), 0, s, arr_id, arr_rev, arr_pos, S,
-                       scaf_start, scaf_len, n_arr, pos2sel);
+    hipLaunchKernelGGL(k_arr_materialize, dim3((n_arr + 255) / 256), dim3(256), 0, s, packed, S, scaf_start, scaf_len,
+                       n_arr, pos2sel);
 }
 
-// closed-form objective of the permutation held in LDS (same arithmetic as k_p2_score)
-__device__ __forceinline__ double score_lds_perm(const double* __restrict__ M2, int64_t ld2, const int32_t* p, int n,
-                                                 const double* __restrict__ H, double* s_w)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double hn = H[n - 1];
-    double acc = 0.0;
-    for (int a = wave; a < n - 1; a += 4) {
-        const double* __restrict__ row = M2 + (int64_t)p[a] * ld2;
-        for (int b = a + 1 + lane; b < n; b += 64) acc += row[p[b]] * (hn - H[b - a - 1]);
-    }
-    acc = wave_sum_s(acc);
-    if (lane == 0) s_w[wave] = acc;
-    __syncthreads();
-    return (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
-}
-
-// checkAllScores candidates: block = (gap g, reversed f); perm = arrangement with the new scaffold
-// spliced in at position arr_pos[g].
-__global__ __launch_bounds__(256) void k_p2_score_insert(const double* __restrict__ M2, int64_t ld2,
+// ---- closed-form score of the arrangement itself --------------------------------------------------
+__global__ __launch_bounds__(256) void k_p2_base_partial(const double* __restrict__ M2, int64_t ld2,
                                                          const int32_t* __restrict__ pos2sel, int n_arr,
-                                                         const int32_t* __restrict__ arr_pos, int new_start,
-                                                         int new_len, const double* __restrict__ H, double total,
-                                                         double* __restrict__ scores)
+                                                         const double* __restrict__ H, int n_tot,
+                                                         double* __restrict__ partial)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t* p = reinterpret_cast<int32_t*>(smem);
     __shared__ double s_w[4];
-    const int g = blockIdx.x >> 1, f = blockIdx.x & 1;
-    const int P = arr_pos[g], n = n_arr + new_len;
-    for (int q = threadIdx.x; q < n; q += 256) {
-        int v;
-        if (q < P) v = pos2sel[q];
-        else if (q < P + new_len) { int e = q - P; v = new_start + (f ? new_len - 1 - e : e); }
-        else v = pos2sel[q - new_len];
-        p[q] = v;
-    }
+    for (int q = threadIdx.x; q < n_arr; q += 256) p[q] = pos2sel[q];
     __syncthreads();
-    double sum = score_lds_perm(M2, ld2, p, n, H, s_w);
-    if (threadIdx.x == 0) scores[blockIdx.x] = sum / total;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double hn = H[n_tot - 1];
+    double acc = 0.0;
+    for (int a = blockIdx.x * 4 + wave; a < n_arr - 1; a += gridDim.x * 4) {
+        const double* __restrict__ row = M2 + (int64_t)p[a] * ld2;
+#pragma unroll 4
+        for (int b = a + 1 + lane; b < n_arr; b += 64) acc += row[p[b]] * (hn - H[b - a - 1]);
+    }
+    double sum = block_sum_256(acc, s_w);
+    if (threadIdx.x == 0) partial[blockIdx.x] = sum;
 }
 
-void launch_p2_score_insert(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const int32_t* arr_pos,
-                            int S, int new_start, int new_len, const double* H, double total, double* scores,
-                            hipStream_t s)
+// BASE as partial sums over row slabs: out[0..n_blocks)
+void launch_p2_base_partial(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const double* H, int n_tot,
+                            int n_blocks, double* out, hipStream_t s)
 {
-    size_t lds = (((size_t)(n_arr + new_len) * sizeof(int32_t)) + 15) & ~(size_t)15;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_score_insert), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_p2_score_insert, dim3(2 * (S + 1)), dim3(256), lds, s, M2, ld2, pos2sel, n_arr, arr_pos,
-                       new_start, new_len, H, total, scores);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_base_partial), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    hipLaunchKernelGGL(k_p2_base_partial, dim3(n_blocks), dim3(256), perm_lds_bytes(n_arr), s, M2, ld2, pos2sel, n_arr, H,
+                       n_tot, out);
 }
 
 // ---- insertion, incremental form ------------------------------------------------------------------
@@ -117,49 +111,30 @@ void launch_p2_score_insert(const double* M2, int64_t ld2, const int32_t* pos2se
 //   CROSS(g, r) = new-scaffold x arrangement pairs + pairs inside the new scaffold
 // STRADDLE(g+1) - STRADDLE(g) only involves the scaffold between the two gaps, so all gaps together
 // cost one pass over the sub-matrix instead of one pass per candidate.
-__device__ __forceinline__ double block_sum_256(double v, double* s_w)
-{
-    v = wave_sum_s(v);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
-}
-
-__global__ __launch_bounds__(256) void k_p2_base_partial(const double* __restrict__ M2, int64_t ld2,
-                                                         const int32_t* __restrict__ pos2sel, int n_arr,
-                                                         const double* __restrict__ H, int n_tot,
-                                                         double* __restrict__ partial)
-{
-    __shared__ double s_w[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double hn = H[n_tot - 1];
-    double acc = 0.0;
-    for (int a = blockIdx.x * 4 + wave; a < n_arr - 1; a += gridDim.x * 4) {
-        const double* __restrict__ row = M2 + (int64_t)pos2sel[a] * ld2;
-        for (int b = a + 1 + lane; b < n_arr; b += 64) acc += row[pos2sel[b]] * (hn - H[b - a - 1]);
-    }
-    double sum = block_sum_256(acc, s_w);
-    if (threadIdx.x == 0) partial[blockIdx.x] = sum;
-}
-
 __global__ __launch_bounds__(256) void k_p2_insert_straddle(const double* __restrict__ M2, int64_t ld2,
                                                             const int32_t* __restrict__ pos2sel, int n_arr,
                                                             const int32_t* __restrict__ arr_pos, int L,
                                                             const double* __restrict__ H, double* __restrict__ D)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int32_t* p = reinterpret_cast<int32_t*>(smem);
     __shared__ double s_w[4];
+    for (int q = threadIdx.x; q < n_arr; q += 256) p[q] = pos2sel[q];
+    __syncthreads();
     const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P0 = arr_pos[g], P1 = arr_pos[g + 1];
     double acc = 0.0;
     for (int u = P0 + wave; u < P1; u += 4) {             // bins of the scaffold between gap g and g+1
-        const double* __restrict__ row = M2 + (int64_t)pos2sel[u] * ld2;
+        const double* __restrict__ row = M2 + (int64_t)p[u] * ld2;
+#pragma unroll 4
         for (int a = lane; a < P0; a += 64) {               // pairs (a, u) stop straddling
             int d = u - a;
-            acc -= row[pos2sel[a]] * (H[d + L - 1] - H[d - 1]);
+            acc -= row[p[a]] * (H[d + L - 1] - H[d - 1]);
         }
+#pragma unroll 4
         for (int b = P1 + lane; b < n_arr; b += 64) {       // pairs (u, b) start straddling
             int d = b - u;
-            acc += row[pos2sel[b]] * (H[d + L - 1] - H[d - 1]);
+            acc += row[p[b]] * (H[d + L - 1] - H[d - 1]);
         }
     }
     double sum = block_sum_256(acc, s_w);
@@ -171,7 +146,11 @@ __global__ __launch_bounds__(256) void k_p2_insert_cross(const double* __restric
                                                          const int32_t* __restrict__ arr_pos, int new_start, int L,
                                                          const double* __restrict__ H, double* __restrict__ cross)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int32_t* p = reinterpret_cast<int32_t*>(smem);
     __shared__ double s_w[4];
+    for (int q = threadIdx.x; q < n_arr; q += 256) p[q] = pos2sel[q];
+    __syncthreads();
     const int g = blockIdx.x >> 1, r = blockIdx.x & 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P = arr_pos[g];
     const double hn = H[n_arr + L - 1];
@@ -179,9 +158,10 @@ __global__ __launch_bounds__(256) void k_p2_insert_cross(const double* __restric
     for (int e = wave; e < L; e += 4) {
         const int xe = new_start + (r ? L - 1 - e : e);
         const double* __restrict__ row = M2 + (int64_t)xe * ld2;
+#pragma unroll 4
         for (int q = lane; q < n_arr; q += 64) {
             int d = q < P ? (P + e - q) : (q + L - (P + e));
-            acc += row[pos2sel[q]] * (hn - H[d - 1]);
+            acc += row[p[q]] * (hn - H[d - 1]);
         }
         for (int e2 = e + 1 + lane; e2 < L; e2 += 64) {
             int x2 = new_start + (r ? L - 1 - e2 : e2);
@@ -196,76 +176,71 @@ void launch_p2_insert_delta(const double* M2, int64_t ld2, const int32_t* pos2se
                             int S, int new_start, int L, const double* H, int n_base_blocks, double* out, hipStream_t s)
 {
     // out: [n_base_blocks partial sums of BASE][S straddle increments][2(S+1) cross terms]
-    hipLaunchKernelGGL(k_p2_base_partial, dim3(n_base_blocks), dim3(256), 0, s, M2, ld2, pos2sel, n_arr, H, n_arr + L, out);
-    hipLaunchKernelGGL(k_p2_insert_straddle, dim3(S), dim3(256), 0, s, M2, ld2, pos2sel, n_arr, arr_pos, L, H,
+    const size_t lds = perm_lds_bytes(n_arr);
+    launch_p2_base_partial(M2, ld2, pos2sel, n_arr, H, n_arr + L, n_base_blocks, out, s);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_insert_straddle), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_insert_cross), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    hipLaunchKernelGGL(k_p2_insert_straddle, dim3(S), dim3(256), lds, s, M2, ld2, pos2sel, n_arr, arr_pos, L, H,
                        out + n_base_blocks);
-    hipLaunchKernelGGL(k_p2_insert_cross, dim3(2 * (S + 1)), dim3(256), 0, s, M2, ld2, pos2sel, n_arr, arr_pos, new_start,
+    hipLaunchKernelGGL(k_p2_insert_cross, dim3(2 * (S + 1)), dim3(256), lds, s, M2, ld2, pos2sel, n_arr, arr_pos, new_start,
                        L, H, out + n_base_blocks + S);
 }
 
-// score of the arrangement itself (one candidate): perm = pos2sel
-__global__ __launch_bounds__(256) void k_p2_score_arr(const double* __restrict__ M2, int64_t ld2,
-                                                      const int32_t* __restrict__ pos2sel, int n_arr,
-                                                      const double* __restrict__ H, double total,
-                                                      double* __restrict__ score)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int32_t* p = reinterpret_cast<int32_t*>(smem);
-    __shared__ double s_w[4];
-    for (int q = threadIdx.x; q < n_arr; q += 256) p[q] = pos2sel[q];
-    __syncthreads();
-    double sum = score_lds_perm(M2, ld2, p, n_arr, H, s_w);
-    if (threadIdx.x == 0) score[0] = sum / total;
-}
-
-void launch_p2_score_arr(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const double* H,
-                         double total, double* score, hipStream_t s)
-{
-    size_t lds = (((size_t)n_arr * sizeof(int32_t)) + 15) & ~(size_t)15;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_score_arr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_p2_score_arr, dim3(1), dim3(256), lds, s, M2, ld2, pos2sel, n_arr, H, total, score);
-}
-
 // ---- window: G table ----------------------------------------------------------------------------
-// block x = window bin at current position p0+x; its row of M2 restricted to the positions outside
-// [p0, p0+m) is staged through LDS in tiles; lane t accumulates G[x][t].
-static constexpr int G_TILE = 4096;
+// block x = window bin at current position p0+x.  Its row of M2, restricted to the positions outside
+// [p0, p0+m), is staged through LDS in tiles; the 256 lanes form a 64 (slot t) x 4 (quarter of the
+// tile) grid, each lane keeping one accumulator per 64 slots, and the four quarters are added at
+// the end.
+static constexpr int G_TILE = 2048;
+static constexpr int G_TMAX = 8;                        // up to 512 window bins per pass
 
 __global__ __launch_bounds__(256) void k_p2_window_G(const double* __restrict__ M2, int64_t ld2,
                                                      const int32_t* __restrict__ pos2sel, int n, int p0, int m,
                                                      const double* __restrict__ H, double* __restrict__ G)
 {
     __shared__ double vals[G_TILE];
-    const int x = blockIdx.x, tid = threadIdx.x;
+    __shared__ double part[4][64];
+    const int x = blockIdx.x, tid = threadIdx.x, tl = tid & 63, seg = tid >> 6;
     const double* __restrict__ row = M2 + (int64_t)pos2sel[p0 + x] * ld2;
     const double hn = H[n - 1];
-    const int n_out = n - m, p1 = p0 + m;
-    // per-lane accumulators for t = tid, tid+256, ... (m is at most a few thousand)
-    for (int t0 = 0; t0 < m; t0 += 256) {
-        const int t = t0 + tid;
-        double acc = 0.0;
+    const int n_out = n - m;
+    for (int tbase = 0; tbase < m; tbase += 64 * G_TMAX) {
+        double acc[G_TMAX];
+#pragma unroll
+        for (int i = 0; i < G_TMAX; i++) acc[i] = 0.0;
         for (int base = 0; base < n_out; base += G_TILE) {
             const int cnt = n_out - base < G_TILE ? n_out - base : G_TILE;
             __syncthreads();
             for (int e = tid; e < cnt; e += 256) {
                 int qq = base + e;
-                int q = qq < p0 ? qq : qq + m;            // skip the window
-                vals[e] = row[pos2sel[q]];
+                vals[e] = row[pos2sel[qq < p0 ? qq : qq + m]];          // skip the window
             }
             __syncthreads();
-            if (t < m) {
-                const int pt = p0 + t;
-                for (int e = 0; e < cnt; e++) {
-                    int qq = base + e;
-                    int q = qq < p0 ? qq : qq + m;
-                    int d = q < p0 ? pt - q : q - pt;     // q < p0 <= pt  or  pt < p1 <= q
-                    acc += vals[e] * (hn - H[d - 1]);
+            const int e0 = (cnt * seg) >> 2, e1 = (cnt * (seg + 1)) >> 2;
+#pragma unroll
+            for (int i = 0; i < G_TMAX; i++) {
+                const int t = tbase + i * 64 + tl;
+                if (t < m) {
+                    const int pt = p0 + t;
+                    double a = acc[i];
+                    for (int e = e0; e < e1; e++) {
+                        int qq = base + e;
+                        int d = qq < p0 ? pt - qq : qq + m - pt;
+                        a += vals[e] * (hn - H[d - 1]);
+                    }
+                    acc[i] = a;
                 }
             }
         }
-        if (t < m) G[(int64_t)x * m + t] = acc;
+#pragma unroll
+        for (int i = 0; i < G_TMAX; i++) {
+            __syncthreads();
+            part[seg][tl] = acc[i];
+            __syncthreads();
+            const int t = tbase + i * 64 + tl;
+            if (seg == 0 && t < m) G[(int64_t)x * m + t] = (part[0][tl] + part[1][tl]) + (part[2][tl] + part[3][tl]);
+        }
     }
-    (void)p1;
 }
 
 void launch_p2_window_G(const double* M2, int64_t ld2, const int32_t* pos2sel, int n, int p0, int m, const double* H,
@@ -279,11 +254,11 @@ void launch_p2_window_G(const double* M2, int64_t ld2, const int32_t* pos2sel, i
 // block = candidate (order o, orientation r) of the k window scaffolds.  Slot j of the candidate holds
 // window scaffold jj = orders[o][j] laid down reversed iff orients[r][j]; a bin's window-local index
 // x is its offset inside the CURRENT window layout (that is how G is indexed).
-__global__ __launch_bounds__(64) void k_p2_window_delta(
-    const double* __restrict__ M2, int64_t ld2, int n, int m, int k, const int32_t* __restrict__ win_id,
-    const uint8_t* __restrict__ win_rev, const int32_t* __restrict__ win_off, const int32_t* __restrict__ scaf_start,
-    const int32_t* __restrict__ scaf_len, const int8_t* __restrict__ orders, const uint8_t* __restrict__ orients,
-    int n_ori, const double* __restrict__ H, const double* __restrict__ G, double* __restrict__ delta)
+__global__ __launch_bounds__(64) void k_p2_window_delta(const double* __restrict__ M2, int64_t ld2, int n, int m, int k,
+                                                        WindowDesc w, const int8_t* __restrict__ orders,
+                                                        const uint8_t* __restrict__ orients, int n_ori,
+                                                        const double* __restrict__ H, const double* __restrict__ G,
+                                                        double* __restrict__ delta)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t* useq = reinterpret_cast<int32_t*>(smem);          // selection index at slot t
@@ -293,15 +268,15 @@ __global__ __launch_bounds__(64) void k_p2_window_delta(
     const uint8_t* __restrict__ ori = orients + (int64_t)(c % n_ori) * k;
     int slot_off[9];
     slot_off[0] = 0;
-    for (int j = 0; j < k; j++) slot_off[j + 1] = slot_off[j] + scaf_len[win_id[ord[j]]];
+    for (int j = 0; j < k; j++) slot_off[j + 1] = slot_off[j] + w.len[ord[j]];
     for (int t = lane; t < m; t += 64) {
         int j = 0;
         while (j + 1 < k && slot_off[j + 1] <= t) j++;
-        const int jj = ord[j], sc = win_id[jj], len = scaf_len[sc];
+        const int jj = ord[j], len = w.len[jj];
         const int ep = t - slot_off[j];
         const int e = ori[j] ? len - 1 - ep : ep;              // offset inside the scaffold, selection order
-        useq[t] = scaf_start[sc] + e;
-        xseq[t] = win_off[jj] + (win_rev[jj] ? len - 1 - e : e);
+        useq[t] = w.start[jj] + e;
+        xseq[t] = w.off[jj] + (w.rev[jj] ? len - 1 - e : e);
     }
     __syncthreads();
     const double hn = H[n - 1];
@@ -315,15 +290,14 @@ __global__ __launch_bounds__(64) void k_p2_window_delta(
     if (lane == 0) delta[c] = acc;
 }
 
-void launch_p2_window_delta(const double* M2, int64_t ld2, int n, int m, int k, const int32_t* win_id,
-                            const uint8_t* win_rev, const int32_t* win_off, const int32_t* scaf_start,
-                            const int32_t* scaf_len, const int8_t* orders, const uint8_t* orients, int n_ord, int n_ori,
-                            const double* H, const double* G, double* delta, hipStream_t s)
+void launch_p2_window_delta(const double* M2, int64_t ld2, int n, int m, int k, const WindowDesc& w, const int8_t* orders,
+                            const uint8_t* orients, int n_ord, int n_ori, const double* H, const double* G,
+                            double* delta, hipStream_t s)
 {
     size_t lds = (((size_t)m * 2 * sizeof(int32_t)) + 15) & ~(size_t)15;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_window_delta), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_p2_window_delta, dim3(n_ord * n_ori), dim3(64), lds, s, M2, ld2, n, m, k, win_id, win_rev,
-                       win_off, scaf_start, scaf_len, orders, orients, n_ori, H, G, delta);
+    hipLaunchKernelGGL(k_p2_window_delta, dim3(n_ord * n_ori), dim3(64), lds, s, M2, ld2, n, m, k, w, orders, orients, n_ori,
+                       H, G, delta);
 }
 
 }  // namespace hicmi
