@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_p2_base_partial(const double* __restric
 void launch_p2_base_partial(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const double* H, int n_tot,
                             int n_blocks, double* out, hipStream_t s)
 {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_base_partial), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_base_partial), hipFuncAttributeMaxDynamicSharedMemorySize, (int)perm_lds_bytes(n_arr));
     hipLaunchKernelGGL(k_p2_base_partial, dim3(n_blocks), dim3(256), perm_lds_bytes(n_arr), s, M2, ld2, pos2sel, n_arr, H,
                        n_tot, out);
 }
@@ -178,8 +178,8 @@ void launch_p2_insert_delta(const double* M2, int64_t ld2, const int32_t* pos2se
     // out: [n_base_blocks partial sums of BASE][S straddle increments][2(S+1) cross terms]
     const size_t lds = perm_lds_bytes(n_arr);
     launch_p2_base_partial(M2, ld2, pos2sel, n_arr, H, n_arr + L, n_base_blocks, out, s);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_insert_straddle), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_insert_cross), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_insert_straddle), hipFuncAttributeMaxDynamicSharedMemorySize, (int)perm_lds_bytes(n_arr));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_insert_cross), hipFuncAttributeMaxDynamicSharedMemorySize, (int)perm_lds_bytes(n_arr));
     hipLaunchKernelGGL(k_p2_insert_straddle, dim3(S), dim3(256), lds, s, M2, ld2, pos2sel, n_arr, arr_pos, L, H,
                        out + n_base_blocks);
     hipLaunchKernelGGL(k_p2_insert_cross, dim3(2 * (S + 1)), dim3(256), lds, s, M2, ld2, pos2sel, n_arr, arr_pos, new_start,
