@@ -30,6 +30,7 @@ SIGNATURES = {
     "hicmi_synchronize": (ctypes.c_int, [_vp]),
     "hicmi_set_contacts_host": (ctypes.c_int, [_vp, _vp, c_i64]),
     "hicmi_set_contacts_device": (ctypes.c_int, [_vp, _vp, c_i64, c_i64]),
+    "hicmi_contacts_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "hicmi_row_sums": (ctypes.c_int, [_vp, _vp, _vp]),
     "hicmi_compact": (ctypes.c_int, [_vp, _vp, c_i64]),
     "hicmi_upgma": (ctypes.c_int, [_vp, _vp, _vp]),
@@ -111,13 +112,34 @@ class Context:
         h = _vp()
         _check(self._lib.hicmi_create(int(device), ctypes.byref(h)))
         self._h = h
+        self.device = int(device)
         self.n = 0
         self._keepalive = None
+        self._workers = []
 
     def close(self):
+        for w in getattr(self, "_workers", []):
+            w.close()
+        self._workers = []
         if getattr(self, "_h", None):
             self._lib.hicmi_destroy(self._h)
             self._h = None
+
+    def workers(self, count: int):
+        """``count`` extra contexts on the same GPU that share this context's contact matrix (no
+        copy): independent work units - Part 2's chromosomes - run on them from host threads."""
+        pool = getattr(self, "_workers", None)
+        if pool is None:
+            pool = self._workers = []
+        ptr, n, ld = _vp(), c_i64(), c_i64()
+        _check(self._lib.hicmi_contacts_device(self._h, ctypes.byref(ptr), ctypes.byref(n), ctypes.byref(ld)))
+        while len(pool) < count:
+            pool.append(Context(self.device))
+        for w in pool[:count]:
+            if getattr(w, "_shared_from", None) != (ptr.value, n.value, ld.value):
+                w.set_contacts_device(ptr.value, n.value, ld.value, keepalive=self)
+                w._shared_from = (ptr.value, n.value, ld.value)
+        return pool[:count]
 
     def __del__(self):
         try:
@@ -281,11 +303,25 @@ class Context:
 
     def timing_enable(self, on=True):
         _check(self._lib.hicmi_timing_enable(self._h, 1 if on else 0))
+        for w in self._workers:
+            w.timing_enable(on)
 
     def timing_reset(self):
         _check(self._lib.hicmi_timing_reset(self._h))
+        for w in self._workers:
+            w.timing_reset()
 
     def timing(self):
+        """Per kernel family: device ms, launches, algorithmic bytes - summed over this context and
+        the worker contexts that share its matrix."""
+        out = self._timing_one()
+        for w in self._workers:
+            for k, v in w._timing_one().items():
+                for f in ("ms", "launches", "bytes"):
+                    out[k][f] += v[f]
+        return out
+
+    def _timing_one(self):
         names = ctypes.create_string_buffer(1024)
         ms = np.zeros(32, np.float64)
         launches = np.zeros(32, np.int64)

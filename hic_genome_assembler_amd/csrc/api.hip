@@ -268,6 +268,14 @@ int hicmi_set_contacts_device(hicmi_ctx* c, const double* d_contacts, int64_t n,
     return alloc_sums(c);
 }
 
+int hicmi_contacts_device(hicmi_ctx* c, void** d_contacts_out, int64_t* n_out, int64_t* ld_out)
+{
+    if (!c || !d_contacts_out || !n_out || !ld_out) return fail(HICMI_EINVAL, "NULL argument");
+    if (!c->dC) return fail(HICMI_EINVAL, "no contact matrix set");
+    *d_contacts_out = (void*)c->dC; *n_out = c->n; *ld_out = c->ldc;
+    return HICMI_OK;
+}
+
 int hicmi_row_sums(hicmi_ctx* c, double* np_sum, double* seq_sum)
 {
     if (!c) return fail(HICMI_EINVAL, "NULL context");

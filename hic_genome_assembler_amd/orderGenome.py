@@ -19,7 +19,9 @@ candidates live and how they are scored:
 from __future__ import annotations
 
 import math
+import os
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -27,6 +29,7 @@ from . import _lib
 from .hostio import Bin, initiateLoci, read_contact_matrix  # noqa: F401
 
 SCORE_HOOK = None      # tests: called with the fast scores of every step, in enumeration order
+WORKERS = int(os.environ.get("HICMI_PART2_WORKERS", "8"))   # chromosomes ordered concurrently (1 = sequential)
 NEAR_TOP = 1e-9        # relative band around a step's best fast score that is re-scored literally
 
 
@@ -549,14 +552,37 @@ def orderChromosome(chromGroup, matrix: GenomeMatrix, binList, nScaffolds=6, sca
 
 def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds=6, scanScaffolds=5, plotChrom=True,
                 showPlot=True, savePlotDir=False, plotTitleSuffix=False):
-    """OG:591-628 (chromosomes are independent; plots are not produced)."""
+    """OG:591-628.  Chromosomes are independent (OG:608-612), so they are ordered concurrently:
+    one host thread + one libhicmi context (own HIP stream, own scratch) per chromosome in flight,
+    all reading the same device-resident contact matrix.  Results are collected in file order.
+    Plots are not produced."""
     t0 = time.time()
-    fullGenomeOrder = []
-    for i, chromGroup in enumerate(chromList):
+    n_workers = 1 if SCORE_HOOK is not None else max(1, min(WORKERS, len(chromList)))
+    matrix.bin_index(binList)
+
+    def one(i, m):
         print("#####################\n#####################")
         print("Working on Chr_" + str(i + 1) + "...")
-        fullGenomeOrder.append(orderChromosome(chromGroup, matrix, binList, nScaffolds=nScaffolds,
-                                               scanScaffolds=scanScaffolds))
+        return orderChromosome(chromList[i], m, binList, nScaffolds=nScaffolds, scanScaffolds=scanScaffolds)
+
+    if n_workers == 1 or not hasattr(matrix.ctx, "workers"):
+        fullGenomeOrder = [one(i, matrix) for i in range(len(chromList))]
+    else:
+        lanes = [matrix] + [GenomeMatrix(c) for c in matrix.ctx.workers(n_workers - 1)]
+        for m in lanes[1:]:
+            m._bin_index, m._bin_index_src = matrix._bin_index, matrix._bin_index_src
+        free = list(lanes)
+        todo = sorted(range(len(chromList)), key=lambda i: -len(chromList[i]))     # largest first
+
+        def run(i):
+            m = free.pop()
+            try:
+                return i, one(i, m)
+            finally:
+                free.append(m)
+        with ThreadPoolExecutor(max_workers=n_workers) as pool:
+            done = dict(pool.map(run, todo))
+        fullGenomeOrder = [done[i] for i in range(len(chromList))]
     print("RunTime for total genome = " + str(time.time() - t0))
     return fullGenomeOrder
 

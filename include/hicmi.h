@@ -55,6 +55,10 @@ int hicmi_synchronize(hicmi_ctx *ctx);
  * dimension ld >= n, in elements) without copying - the caller keeps it alive and unchanged. */
 int hicmi_set_contacts_host(hicmi_ctx *ctx, const double *contacts, int64_t n);
 int hicmi_set_contacts_device(hicmi_ctx *ctx, const double *d_contacts, int64_t n, int64_t ld);
+/* Device address, size and leading dimension of the context's contact matrix, so that further
+ * contexts on the same GPU (e.g. one per chromosome worker thread in Part 2, chromosomes being
+ * independent - OG:608-612) can adopt it with hicmi_set_contacts_device instead of copying it. */
+int hicmi_contacts_device(hicmi_ctx *ctx, void **d_contacts_out, int64_t *n_out, int64_t *ld_out);
 
 /* Row sums, both flavours the reference uses:
  *   np_sum[i]  = row.sum() as NumPy reduces it (pairwise, 8192-element chunks)   S2C:112, S2C:147
