@@ -112,12 +112,15 @@ def main():
         ctx.set_contacts_device(contacts.data_ptr(), n, keepalive=contacts)
         dm = p1.DeviceMatrix(ctx)
         with contextlib.redirect_stdout(io.StringIO()):
+            ta = time.perf_counter()
             cuts = p1.runResident(dm, make_bins(lay, Bin), sizes, f("dendrogramOrder.txt"), f("binGroups.txt"),
                                   f("assessment.txt"), f("chromosomeGroups.txt"), 5, 0.0, .05)
+            last["part1_s"] = time.perf_counter() - ta
             if not args.part1_only:
                 p2.runResident(p2.GenomeMatrix(ctx), dm.kept_bins, f("chromosomeGroups.txt"),
                                f("chromosomeOrders.txt"), f("plotOrder.txt"), args.n_scaffolds, args.scan_scaffolds,
                                lay.resolution)
+        last["part2_s"] = time.perf_counter() - ta - last["part1_s"]
         last["cuts"] = cuts
 
     def barrier():
@@ -167,6 +170,9 @@ def main():
                        "scaffolds": len(lay.scaffold_names), "cuts_found": len(last.get("cuts", [])),
                        "minSize": 5, "modularity": 0, "psig": 0.05, "nScaffolds": args.n_scaffolds,
                        "scanScaffolds": args.scan_scaffolds, "wall_clock_s": ms_per_step / 1e3,
+                       "last_step_part1_s": round(last.get("part1_s", 0.0), 4),
+                       "last_step_part2_s": round(last.get("part2_s", 0.0), 4),
+                       "part2_workers": p2.WORKERS,
                        "parallelism": "1 map per GPU, no collective" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": fam, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -54,6 +54,11 @@ SIGNATURES = {
     "hicmi_p2_score_insertions": (ctypes.c_int, [_vp, ctypes.c_int32, c_dbl, _vp]),
     "hicmi_p2_window_tables": (ctypes.c_int, [_vp, c_i64, _vp, c_i64, _vp, c_i64]),
     "hicmi_p2_score_window": (ctypes.c_int, [_vp, c_i64, c_i64, _vp]),
+    "hicmi_p2_decide_window": (ctypes.c_int, [_vp, c_i64, c_i64, c_dbl, c_dbl, c_dbl, ctypes.POINTER(c_i64),
+                                              ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl)]),
+    "hicmi_p2_decide_insertion": (ctypes.c_int, [_vp, _vp, _vp, c_i64, ctypes.c_int32, ctypes.c_int32,
+                                                 ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_int32),
+                                                 ctypes.POINTER(c_dbl)]),
     "hicmi_timing_reset": (ctypes.c_int, [_vp]),
     "hicmi_timing_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "hicmi_timing_get": (ctypes.c_int, [_vp, ctypes.c_char_p, c_i64, _vp, _vp, _vp, c_i64, ctypes.POINTER(c_i64)]),
@@ -291,6 +296,25 @@ class Context:
         out = np.empty(self._n_window_cand, np.float64)
         _check(self._lib.hicmi_p2_score_window(self._h, int(first), int(k), _ptr(out)))
         return out
+
+    def p2_decide_window(self, first, k, total, floor, cur_fast):
+        """One whole window step; returns (pick or -1, literal best, fast score of the resulting arrangement)."""
+        pick, best, pf = c_i64(), c_dbl(), c_dbl()
+        _check(self._lib.hicmi_p2_decide_window(self._h, int(first), int(k), float(total), float(floor),
+                                                float("nan") if cur_fast is None else float(cur_fast),
+                                                ctypes.byref(pick), ctypes.byref(best), ctypes.byref(pf)))
+        return pick.value, best.value, pf.value
+
+    def p2_decide_insertion(self, ids, rev, new_id, new_rev_now):
+        """One whole checkAllScores step; returns (gap or -1, reversed flag, literal best)."""
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        b = np.ascontiguousarray(rev, dtype=np.uint8)
+        gap, r, best = c_i64(), ctypes.c_int32(), c_dbl()
+        _check(self._lib.hicmi_p2_decide_insertion(self._h, _ptr(a), _ptr(b), len(a), int(new_id), int(new_rev_now),
+                                                   ctypes.byref(gap), ctypes.byref(r), ctypes.byref(best)))
+        self._arr_sig = a.tobytes() + b.tobytes()
+        self._arr_len = len(a)
+        return gap.value, r.value, best.value
 
     # ---- misc
     def synchronize(self):

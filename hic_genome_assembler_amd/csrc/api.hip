@@ -10,6 +10,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/hicmi.h"
@@ -85,6 +86,10 @@ struct hicmi_ctx {
     int32_t* d_pos2sel = nullptr; int64_t pos_cap = 0; int64_t n_arr = 0;
     int8_t* d_orders = nullptr; uint8_t* d_orients = nullptr; int64_t ord_cap = 0, ori_cap = 0;
     int tab_k = 0; int64_t n_orders = 0, n_orients = 0;
+    std::vector<int8_t> h_orders; std::vector<uint8_t> h_orients;
+    std::vector<int32_t> h_pos2sel;                              // host mirror of the arrangement's bin order
+    double cache_total = 0.0; bool cache_valid = false;          // literal scores under one total, keyed by bin order
+    std::unordered_map<std::string, double> exact_cache;
     double* d_G = nullptr; int64_t g_cap = 0;
     double* d_delta = nullptr; int64_t delta_cap = 0;
 
@@ -603,6 +608,7 @@ int hicmi_p2_select(hicmi_ctx* c, const int32_t* sel, int64_t n)
     HIPCHK(hipStreamSynchronize(c->stream));
     c->n2 = n; c->ld2 = ld2;
     c->n_scaf = 0; c->n_arr = 0; c->h_arr_id.clear();
+    c->cache_valid = false; c->exact_cache.clear();
     return HICMI_OK;
 }
 
@@ -721,6 +727,13 @@ int hicmi_p2_set_arrangement(hicmi_ctx* c, const int32_t* ids, const uint8_t* re
     if (rc) return rc;
     c->h_arr_id.assign(ids, ids + S); c->h_arr_rev.assign(rev, rev + S); c->h_arr_pos = pos;
     c->n_arr = pos[(size_t)S];
+    c->h_pos2sel.resize((size_t)c->n_arr);
+    for (int64_t j = 0; j < S; j++) {
+        const int32_t st = c->h_scaf_start[(size_t)ids[j]], ln = c->h_scaf_len[(size_t)ids[j]];
+        int32_t* dst = c->h_pos2sel.data() + pos[(size_t)j];
+        if (rev[j]) for (int32_t e = 0; e < ln; e++) dst[e] = st + ln - 1 - e;
+        else        for (int32_t e = 0; e < ln; e++) dst[e] = st + e;
+    }
     c->h_arr_packed.resize((size_t)(3 * S + 1));
     for (int64_t j = 0; j < S; j++) { c->h_arr_packed[(size_t)j] = ids[j]; c->h_arr_packed[(size_t)(2 * S + 1 + j)] = rev[j] ? 1 : 0; }
     for (int64_t j = 0; j <= S; j++) c->h_arr_packed[(size_t)(S + j)] = pos[(size_t)j];
@@ -823,6 +836,8 @@ int hicmi_p2_window_tables(hicmi_ctx* c, int64_t k, const int8_t* orders, int64_
     HIPCHK(hipMemcpyAsync(c->d_orients, orients, (size_t)(n_orients * k), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->tab_k = (int)k; c->n_orders = n_orders; c->n_orients = n_orients;
+    c->h_orders.assign(orders, orders + n_orders * k);
+    c->h_orients.assign(orients, orients + n_orients * k);
     return HICMI_OK;
 }
 
@@ -862,6 +877,192 @@ int hicmi_p2_score_window(hicmi_ctx* c, int64_t first, int64_t k, double* delta_
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(delta_out, c->d_delta, sizeof(double) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return HICMI_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Whole decision steps in one call: fast scores of every candidate (device enumeration), short list
+// of the candidates within 1e-9 of the step's best, literal re-scoring of the short list (cached by
+// bin order under the current total), then the reference's first-strict-maximum scan (OG:349,359,
+// 464,535).  The same logic as SubMatrix.first_strict_max in orderGenome.py, minus ~10 host round trips.
+namespace {
+const double kNearTop = 1e-9;
+
+void use_total(hicmi_ctx* c, double total)
+{
+    if (!c->cache_valid || c->cache_total != total) { c->exact_cache.clear(); c->cache_total = total; c->cache_valid = true; }
+}
+
+// literal scores of rows (each n_used selection indices) under `total`, through the cache
+int literal_scores(hicmi_ctx* c, const std::vector<std::vector<int32_t>>& rows, double total, std::vector<double>& out)
+{
+    out.assign(rows.size(), 0.0);
+    if (rows.empty()) return HICMI_OK;
+    const int64_t n_used = (int64_t)rows[0].size();
+    std::vector<std::string> keys(rows.size());
+    std::vector<size_t> todo;
+    std::unordered_map<std::string, size_t> pending;
+    for (size_t i = 0; i < rows.size(); i++) {
+        keys[i].assign(reinterpret_cast<const char*>(rows[i].data()), rows[i].size() * sizeof(int32_t));
+        if (c->exact_cache.count(keys[i]) || pending.count(keys[i])) continue;
+        pending[keys[i]] = todo.size();
+        todo.push_back(i);
+    }
+    if (!todo.empty()) {
+        std::vector<double> vals(todo.size(), 0.0);
+        if (n_used >= 2) {
+            std::vector<int32_t> flat((size_t)n_used * todo.size());
+            for (size_t t = 0; t < todo.size(); t++) memcpy(flat.data() + t * n_used, rows[todo[t]].data(), sizeof(int32_t) * (size_t)n_used);
+            const int64_t n_cand = (int64_t)todo.size();
+            int rc = ensure(c->d_perms, c->perms_cap, n_cand * n_used);
+            if (rc) return rc;
+            rc = ensure(c->d_scores, c->scores_cap, n_cand);
+            if (rc) return rc;
+            rc = ensure(c->d_T, c->t_cap, 2 * n_cand * n_used);
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(c->d_perms, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice, c->stream));
+            {
+                Timed t(c, F_P2_EXACT, 8.0 * (double)n_cand * 0.5 * (double)n_used * (double)(n_used - 1));
+                launch_p2_score_exact(c->dM2, c->ld2, c->d_perms, (int)n_cand, (int)n_used, total, c->d_T,
+                                      c->d_T + n_cand * n_used, c->d_scores, c->stream);
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(vals.data(), c->d_scores, sizeof(double) * vals.size(), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        for (size_t t = 0; t < todo.size(); t++) c->exact_cache[keys[todo[t]]] = vals[t];
+    }
+    for (size_t i = 0; i < rows.size(); i++) out[i] = c->exact_cache[keys[i]];
+    return HICMI_OK;
+}
+
+// indices of the candidates whose fast score is within kNearTop of max(best fast, floor)
+void short_list(const std::vector<double>& fast, double floor, std::vector<int64_t>& near)
+{
+    near.clear();
+    bool any = false; double top = floor;
+    for (double v : fast) if (std::isfinite(v)) { any = true; if (v > top) top = v; }
+    if (!any) return;
+    const double thr = top - std::fabs(top) * kNearTop;
+    for (size_t i = 0; i < fast.size(); i++) if (std::isfinite(fast[i]) && fast[i] >= thr) near.push_back((int64_t)i);
+}
+}  // namespace
+
+int hicmi_p2_decide_window(hicmi_ctx* c, int64_t first, int64_t k, double total, double floor, double cur_fast,
+                           int64_t* pick_out, double* best_out, double* pick_fast_out)
+{
+    if (!c || !pick_out || !best_out || !pick_fast_out) return fail(HICMI_EINVAL, "NULL argument");
+    const int64_t S = (int64_t)c->h_arr_id.size();
+    if (c->n_arr < 1 || S < 1) return fail(HICMI_EINVAL, "hicmi_p2_set_arrangement has not run");
+    if (k != c->tab_k || c->h_orders.empty()) return fail(HICMI_EINVAL, "hicmi_p2_window_tables has not been called for k = %lld", (long long)k);
+    if (first < 0 || first + k > S) return fail(HICMI_EINVAL, "window out of range");
+    const int64_t n_ord = c->n_orders, n_ori = c->n_orients, n_cand = n_ord * n_ori;
+    *pick_out = -1; *best_out = floor; *pick_fast_out = cur_fast;
+    use_total(c, total);
+    // candidate index of the current configuration: identity order + the window's current signs
+    int64_t c0 = -1;
+    for (int64_t j = 0; j < k; j++) if (c->h_orders[(size_t)j] != j) return fail(HICMI_EINVAL, "orders[0] must be the identity");
+    for (int64_t r = 0; r < n_ori && c0 < 0; r++) {
+        bool same = true;
+        for (int64_t j = 0; j < k; j++) same = same && ((c->h_orients[(size_t)(r * k + j)] != 0) == (c->h_arr_rev[(size_t)(first + j)] != 0));
+        if (same) c0 = r;
+    }
+    if (c0 < 0) return fail(HICMI_EINVAL, "current orientation not in the orientation table");
+    std::vector<double> delta((size_t)n_cand);
+    int rc = hicmi_p2_score_window(c, first, k, delta.data());
+    if (rc) return rc;
+    std::vector<double> fast((size_t)n_cand);
+    if (k == S) for (int64_t i = 0; i < n_cand; i++) fast[(size_t)i] = delta[(size_t)i] / total;
+    else {
+        if (std::isnan(cur_fast)) { rc = hicmi_p2_arrangement_score(c, total, &cur_fast); if (rc) return rc; }
+        for (int64_t i = 0; i < n_cand; i++) fast[(size_t)i] = cur_fast + (delta[(size_t)i] - delta[(size_t)c0]) / total;
+    }
+    std::vector<int64_t> near;
+    short_list(fast, floor, near);
+    if (near.empty()) { *pick_fast_out = cur_fast; return HICMI_OK; }
+    const int p0 = c->h_arr_pos[(size_t)first], p1 = c->h_arr_pos[(size_t)(first + k)];
+    std::vector<std::vector<int32_t>> rows(near.size());
+    for (size_t q = 0; q < near.size(); q++) {
+        const int64_t cand = near[q];
+        const int8_t* ord = c->h_orders.data() + (cand / n_ori) * k;
+        const uint8_t* ori = c->h_orients.data() + (cand % n_ori) * k;
+        std::vector<int32_t>& row = rows[q];
+        row.reserve((size_t)c->n_arr);
+        row.insert(row.end(), c->h_pos2sel.begin(), c->h_pos2sel.begin() + p0);
+        for (int64_t j = 0; j < k; j++) {
+            const int32_t sc = c->h_arr_id[(size_t)(first + ord[j])];
+            const int32_t st = c->h_scaf_start[(size_t)sc], ln = c->h_scaf_len[(size_t)sc];
+            if (ori[j]) for (int32_t e = 0; e < ln; e++) row.push_back(st + ln - 1 - e);
+            else        for (int32_t e = 0; e < ln; e++) row.push_back(st + e);
+        }
+        row.insert(row.end(), c->h_pos2sel.begin() + p1, c->h_pos2sel.end());
+    }
+    std::vector<double> lit;
+    rc = literal_scores(c, rows, total, lit);
+    if (rc) return rc;
+    double best = floor; int64_t pick = -1;
+    for (size_t q = 0; q < near.size(); q++) if (lit[q] > best) { best = lit[q]; pick = near[q]; }
+    *pick_out = pick; *best_out = best;
+    *pick_fast_out = pick >= 0 ? fast[(size_t)pick] : cur_fast;
+    return HICMI_OK;
+}
+
+int hicmi_p2_decide_insertion(hicmi_ctx* c, const int32_t* ids, const uint8_t* rev, int64_t S, int32_t new_id,
+                              int32_t new_rev_now, int64_t* gap_out, int32_t* rev_out, double* best_out)
+{
+    if (!c || !ids || !rev || !gap_out || !rev_out || !best_out || S < 1) return fail(HICMI_EINVAL, "bad arguments");
+    if (c->n_scaf < 1) return fail(HICMI_EINVAL, "hicmi_p2_layout has not run");
+    if (new_id < 0 || new_id >= c->n_scaf) return fail(HICMI_EINVAL, "new scaffold out of range");
+    *gap_out = -1; *rev_out = 0; *best_out = 0.0;
+    // total of the sub-matrix in the order "ordered scaffolds, then the new one" (OG:484-487 -> OG:343)
+    std::vector<int32_t> ids2(ids, ids + S); ids2.push_back(new_id);
+    std::vector<uint8_t> rev2(rev, rev + S); rev2.push_back(new_rev_now ? 1 : 0);
+    int rc = hicmi_p2_set_arrangement(c, ids2.data(), rev2.data(), S + 1);
+    if (rc) return rc;
+    double total = 0.0;
+    rc = hicmi_p2_arrangement_total(c, &total);
+    if (rc) return rc;
+    use_total(c, total);
+    rc = hicmi_p2_set_arrangement(c, ids, rev, S);
+    if (rc) return rc;
+    const int64_t gaps = S + 1;
+    std::vector<double> by_gap_rev((size_t)(2 * gaps));
+    rc = hicmi_p2_score_insertions(c, new_id, total, by_gap_rev.data());
+    if (rc) return rc;
+    // enumeration order of OG:344-365: gap i tests the current orientation, then the flipped one, and the
+    // scaffold stays flipped for the next gap
+    std::vector<double> fast((size_t)(2 * gaps));
+    std::vector<int32_t> tag_rev((size_t)(2 * gaps));
+    int32_t o = new_rev_now ? 1 : 0;
+    for (int64_t i = 0; i < gaps; i++) {
+        tag_rev[(size_t)(2 * i)] = o; tag_rev[(size_t)(2 * i + 1)] = o ^ 1;
+        fast[(size_t)(2 * i)] = by_gap_rev[(size_t)(2 * i + o)];
+        fast[(size_t)(2 * i + 1)] = by_gap_rev[(size_t)(2 * i + (o ^ 1))];
+        o ^= 1;
+    }
+    std::vector<int64_t> near;
+    short_list(fast, 0.0, near);
+    if (near.empty()) return HICMI_OK;
+    const int32_t st = c->h_scaf_start[(size_t)new_id], ln = c->h_scaf_len[(size_t)new_id];
+    std::vector<std::vector<int32_t>> rows(near.size());
+    for (size_t q = 0; q < near.size(); q++) {
+        const int64_t g = near[q] / 2;
+        const int32_t r = tag_rev[(size_t)near[q]];
+        const int P = c->h_arr_pos[(size_t)g];
+        std::vector<int32_t>& row = rows[q];
+        row.reserve((size_t)(c->n_arr + ln));
+        row.insert(row.end(), c->h_pos2sel.begin(), c->h_pos2sel.begin() + P);
+        if (r) for (int32_t e = 0; e < ln; e++) row.push_back(st + ln - 1 - e);
+        else   for (int32_t e = 0; e < ln; e++) row.push_back(st + e);
+        row.insert(row.end(), c->h_pos2sel.begin() + P, c->h_pos2sel.end());
+    }
+    std::vector<double> lit;
+    rc = literal_scores(c, rows, total, lit);
+    if (rc) return rc;
+    double best = 0.0; int64_t pick = -1;
+    for (size_t q = 0; q < near.size(); q++) if (lit[q] > best) { best = lit[q]; pick = near[q]; }
+    if (pick >= 0) { *gap_out = pick / 2; *rev_out = tag_rev[(size_t)pick]; *best_out = best; }
     return HICMI_OK;
 }
 

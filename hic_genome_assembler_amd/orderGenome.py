@@ -413,6 +413,12 @@ def _window_scores(view: SubMatrix, arrangement, first, k, known_fast=None):
     return fast, row_of
 
 
+def _fused(ctx):
+    """Use the one-call decision steps of libhicmi (hicmi_p2_decide_*) unless a test wants to see
+    every fast score (SCORE_HOOK) or the context is a test double without them."""
+    return SCORE_HOOK is None and hasattr(ctx, "p2_decide_window")
+
+
 # ---- search ---------------------------------------------------------------------------------------
 def bruteForceBestScore(sObjList, scaffDict, matrix: SubMatrix, orderDict):
     """OG:432-473: all k!/2 orders x 2^k orientations of the k largest scaffolds in one launch."""
@@ -425,8 +431,13 @@ def bruteForceBestScore(sObjList, scaffDict, matrix: SubMatrix, orderDict):
               + ",".join(str(e) for e in names))
         return [names[i] for i in orders[0]], list(orients[0]), 0.0
     print("Initial permutations to test " + str(len(orders) * len(orients)) + "...")
-    fast, row_of = _window_scores(matrix, sObjList, 0, k)
-    best, best_c = matrix.first_strict_max(fast, 0., row_of)          # first strict maximum above 0. (OG:464)
+    if _fused(matrix.ctx):
+        matrix.layout.tables(k)
+        matrix.ctx.p2_set_arrangement(*matrix.layout.describe(sObjList))
+        best, best_c, _pf = matrix.ctx.p2_decide_window(0, k, total, 0., None)
+    else:
+        fast, row_of = _window_scores(matrix, sObjList, 0, k)
+        best, best_c = matrix.first_strict_max(fast, 0., row_of)      # first strict maximum above 0. (OG:464)
     # the enumeration leaves every scaffold in the last candidate's orientation (OG:459)
     reorderScaffList([names[i] for i in orders[-1]], orients[-1], scaffDict)
     if best < 0:
@@ -440,10 +451,19 @@ def checkAllScores(adjMat: SubMatrix, orderDict, orderedScaffs, scaffToCheck):
     per gap and stays flipped, so the orientation tried first alternates with the gap index."""
     layout, ctx = adjMat.layout, adjMat.ctx
     gaps = len(orderedScaffs) + 1
-    total = adjMat.total()
     flip = {"+": "-", "-": "+"}
     new_id = layout.sid[scaffToCheck.name]
     ids, rev = layout.describe(orderedScaffs)
+    if _fused(ctx) and len(ids) > 0:
+        gap, r, bestCost = ctx.p2_decide_insertion(ids, rev, new_id, scaffToCheck.orientation == "-")
+        bestGap, bestOrient = (gap, "-" if r else "+") if gap >= 0 else (0, "+")
+        if gaps % 2 == 1:                               # one flip per gap (OG:356)
+            scaffToCheck.flipOrientation()
+        if scaffToCheck.orientation != bestOrient:
+            scaffToCheck.flipOrientation()
+        orderedScaffs.insert(bestGap, scaffToCheck)
+        return orderedScaffs, bestCost
+    total = adjMat.total()
     tags, o = [], scaffToCheck.orientation
     for i in range(gaps):
         tags += [(i, o), (i, flip[o])]
@@ -501,12 +521,18 @@ def scanOrdering(orderedScaffolds, scaffoldDict, orderDict, matrix: GenomeMatrix
         improved = False
         print("Working on round " + str(roundNumber + 1) + " of final step...")
         for i in range(0, len(orderedScaffolds) - w + 1):
-            if cur_fast is None:
-                ids, rev = adjMat.layout.describe(orderedScaffolds)
-                adjMat.ctx.p2_set_arrangement(ids, rev)
-                cur_fast = adjMat.ctx.p2_arrangement_score(total)
-            fast, row_of = _window_scores(adjMat, orderedScaffolds, i, w, known_fast=cur_fast)
-            pick, bestCost = adjMat.first_strict_max(fast, bestCost, row_of)   # strict '>' vs the global best (OG:535)
+            if _fused(adjMat.ctx):
+                adjMat.layout.tables(w)
+                adjMat.ctx.p2_set_arrangement(*adjMat.layout.describe(orderedScaffolds))
+                pick, bestCost, cur_fast = adjMat.ctx.p2_decide_window(i, w, total, bestCost, cur_fast)
+                fast = None
+            else:
+                if cur_fast is None:
+                    ids, rev = adjMat.layout.describe(orderedScaffolds)
+                    adjMat.ctx.p2_set_arrangement(ids, rev)
+                    cur_fast = adjMat.ctx.p2_arrangement_score(total)
+                fast, row_of = _window_scores(adjMat, orderedScaffolds, i, w, known_fast=cur_fast)
+                pick, bestCost = adjMat.first_strict_max(fast, bestCost, row_of)   # strict '>' vs the global best (OG:535)
             if pick >= 0:
                 improved = True
                 o, r = orders[pick // len(orients)], orients[pick % len(orients)]
@@ -515,7 +541,8 @@ def scanOrdering(orderedScaffolds, scaffoldDict, orderDict, matrix: GenomeMatrix
                 outside = {s.name: s.orientation for s in orderedScaffolds}
                 bestOrder = names[:i] + [window[j].name for j in o] + names[i + w:]
                 bestOrientation = ([outside[nm] for nm in names[:i]] + list(r) + [outside[nm] for nm in names[i + w:]])
-                cur_fast = float(fast[pick])
+                if fast is not None:
+                    cur_fast = float(fast[pick])
             orderedScaffolds, _nodes = reorderScaffList(bestOrder, bestOrientation, scaffoldDict)
         roundNumber += 1
         if not improved:

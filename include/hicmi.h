@@ -164,6 +164,24 @@ int hicmi_p2_window_tables(hicmi_ctx *ctx, int64_t k, const int8_t *orders, int6
  * n_orders * n_orients doubles. */
 int hicmi_p2_score_window(hicmi_ctx *ctx, int64_t first, int64_t k, double *delta_out);
 
+/* Whole decision steps (what the drop-in Part 2 calls in its inner loops): fast scores of all
+ * candidates, short list within 1e-9 of the best, literal re-scoring of the short list (cached by
+ * bin order under `total`), then the reference's "first strict maximum above bestCost" rule
+ * (OG:349,359,464,535) - identical decisions to doing the same with the entry points above.
+ *
+ * Window of k scaffolds at arrangement index `first` (k == S is bruteForceBestScore).  floor is the
+ * incoming bestCost; cur_fast the fast score of the current arrangement (NaN: computed here).
+ * pick_out = winning candidate index or -1; best_out = its literal score (or floor);
+ * pick_fast_out = fast score of the arrangement that is current after applying the pick. */
+int hicmi_p2_decide_window(hicmi_ctx *ctx, int64_t first, int64_t k, double total, double floor, double cur_fast,
+                           int64_t *pick_out, double *best_out, double *pick_fast_out);
+/* checkAllScores (OG:332-372) for scaffold new_id against the arrangement (ids, rev): computes the
+ * literal total of "arrangement + new scaffold last" (OG:484-487, 343), scores the 2(S+1) candidates in
+ * the reference's enumeration order (orientation tested first alternates with the gap, starting from
+ * new_rev_now) and returns the winning gap / orientation (gap_out = -1: nothing scored above 0). */
+int hicmi_p2_decide_insertion(hicmi_ctx *ctx, const int32_t *ids, const uint8_t *rev, int64_t S, int32_t new_id,
+                              int32_t new_rev_now, int64_t *gap_out, int32_t *rev_out, double *best_out);
+
 /* ---- timing ----------------------------------------------------------------------------------
  * Accumulated device time (HIP events on the context stream) per kernel family since the last
  * reset, for bench.py's roofline object.  names_out: caller buffer receiving ';'-separated names;

@@ -350,6 +350,16 @@ def test_pipeline_files_identical_to_reference(hic, name, tmp_path):
     assert np.max(np.abs(got[ok] - ref[ok]) / np.abs(ref[ok])) < 1e-10
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_pipeline_fused_decision_steps_identical_to_reference(hic, name, tmp_path):
+    """The production path: Part 2's inner loops as single C calls (hicmi_p2_decide_window /
+    _insertion) and chromosomes ordered concurrently on worker contexts."""
+    out = _run_product(name, tmp_path, record=None)
+    for fn in gc.OUTPUT_FILES:
+        with open(os.path.join(out, fn)) as fh:
+            assert fh.read() == gc.golden_text(name, fn), fn
+
+
 def test_cli_drop_in(hic, tmp_path):
     from hic_genome_assembler_amd import run_hicAssembler, synth
     name = "n160"
