@@ -386,7 +386,7 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         c->ldw = ldw; c->w_rows = n;
         free_dev(c->d_size); free_dev(c->d_chain); free_dev(c->d_zraw); free_dev(c->d_status);
         c->d_size = c->d_chain = c->d_status = nullptr; c->d_zraw = nullptr;
-        HIPCHK(hipMalloc((void**)&c->d_size, sizeof(int) * (size_t)std::max<int64_t>(n, 16)));
+        HIPCHK(hipMalloc((void**)&c->d_size, nnchain_workspace_bytes((int)n)));
         HIPCHK(hipMalloc((void**)&c->d_chain, sizeof(int) * (size_t)(n + 2)));
         HIPCHK(hipMalloc((void**)&c->d_zraw, sizeof(double) * 4 * (size_t)n));
         HIPCHK(hipMalloc((void**)&c->d_status, sizeof(int)));
@@ -400,21 +400,24 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         // nominal algorithmic traffic of SciPy's nn_chain: <=3(n-1) row scans + per merge two row reads,
         // one row write and one column write of 8-byte elements
         Timed t(c, F_NNCHAIN, 8.0 * 7.0 * (double)n * (double)(n - 1));
-        unsigned long long* prof = getenv("HICMI_NNCHAIN_PROFILE") ? reinterpret_cast<unsigned long long*>(c->d_size) : nullptr;
-        launch_nnchain(c->dW, ldw, (int)n, c->d_chain, c->d_zraw, c->d_status, prof, c->stream);
+        const char* cap = getenv("HICMI_NNCHAIN_DCAP");           // merges between two column flushes (tests shrink it)
+        launch_nnchain(c->dW, ldw, (int)n, c->d_chain, c->d_zraw, c->d_size, getenv("HICMI_NNCHAIN_PROFILE") != nullptr,
+                       cap ? atoi(cap) : 1024, c->stream);
     }
     HIPCHK(hipGetLastError());
     int status = 0;
     c->zraw.assign((size_t)(4 * (n - 1)), 0.0);
-    HIPCHK(hipMemcpyAsync(&status, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    int nn_state[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(nn_state, nnchain_state_ptr(c->d_size), sizeof(nn_state), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->zraw.data(), c->d_zraw, sizeof(double) * 4 * (size_t)(n - 1), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (getenv("HICMI_NNCHAIN_PROFILE")) {
         unsigned long long pr[5] = {0, 0, 0, 0, 0};
-        HIPCHK(hipMemcpy(pr, c->d_size, sizeof(pr), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(pr, nnchain_prof_ptr(c->d_size), sizeof(pr), hipMemcpyDeviceToHost));
         fprintf(stderr, "[hicmi] nnchain phases (ms @100MHz): bookkeeping %.2f scan %.2f pick %.2f merge %.2f update %.2f\n",
                 pr[0] / 1e5, pr[1] / 1e5, pr[2] / 1e5, pr[3] / 1e5, pr[4] / 1e5);
     }
+    status = nn_state[5] != 0 || nn_state[0] != (int)(n - 1);
     if (status != 0) return fail(HICMI_ESTATE, "nn-chain kernel stopped on its guard (NaN distances or an internal error)");
     std::vector<double> Z((size_t)(4 * (n - 1)));
     rc = hicmi_label_linkage(c->zraw.data(), n, Z.data());

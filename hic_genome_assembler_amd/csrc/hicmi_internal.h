@@ -11,8 +11,12 @@ void launch_row_sums(const double* C, int64_t ldc, int n, double* np_sum, double
 void launch_compact(const double* src, int64_t ld_src, const int32_t* keep, int n_keep, double* dst, int64_t ld_dst,
                     hipStream_t s);
 void launch_build_w(const double* C, int64_t ldc, const double* np_sum, int n, double* W, int64_t ldw, hipStream_t s);
-void launch_nnchain(double* W, int64_t ldw, int n, int* chain, double* zraw, int* status, unsigned long long* prof,
+// k_nnchain.hip
+size_t nnchain_workspace_bytes(int n);
+void launch_nnchain(double* W, int64_t ldw, int n, int* chain, double* zraw, void* workspace, bool profile, int dcap,
                     hipStream_t s);
+const int* nnchain_state_ptr(void* workspace);                    // [0] merges done ... [5] guard tripped
+const unsigned long long* nnchain_prof_ptr(void* workspace);      // 5 phase totals (100 MHz ticks)
 void launch_cut_count(const uint16_t* rank, int64_t ldr, int row0, int nrows, int lo, int mode, int cparam,
                       int32_t* x_out, hipStream_t s);
 void launch_hyper_flags(const int32_t* x, int nrows, int mode, int L_fixed, int64_t M, double psig, uint8_t* sig,

@@ -1,0 +1,313 @@
+// k_nnchain.hip - UPGMA by nearest-neighbour chain: SciPy's _hierarchy.nn_chain for
+// method='average' (scaffoldToChromosomes.py:197; algorithm restated in SURVEY.md A3 and
+// oracle/oracle_c.c), bit for bit.
+//
+// The algorithm is a chain of ~3(n-1) DEPENDENT O(n) steps - row scans for the nearest neighbour and
+// Lance-Williams updates - each far too small to amortise a grid-wide barrier (a 16k-bin row is
+// 128 KB; an XCD-hierarchical grid barrier costs ~5 us, about what one CU needs to stream the row).
+// So the chain runs as ONE persistent 1024-lane workgroup:
+//   scan   : lanes stream row x of W with 16-byte loads, keep (min, lowest index) per lane,
+//            wave-shuffle + LDS arg-min; strict '<' + index order == SciPy's tie rule, and the
+//            previous chain element is preferred exactly as SciPy does;
+//   update : (nx*d_xi + ny*d_yi)/(nx+ny) with five separate fp64 roundings; row y is rewritten with
+//            coalesced stores.
+// What a single CU cannot do cheaply is the other half of keeping W symmetric: scattering column y
+// (n 8-byte stores to n different lines per merge).  That is DEFERRED: a merged cluster becomes
+// "dirty" (time-stamped in LDS); for a pair (a, b) the row of the cluster that merged LAST is
+// authoritative, so scans and updates read a dirty partner's value from the partner's own fresh row
+// (one extra gathered load per dirty cluster, all in flight together).  After DCAP merges the
+// workgroup saves its state and exits; k_nn_flush - a full-chip kernel - writes all dirty columns at
+// once, and the next epoch resumes.  Launches are queued back to back without host synchronisation.
+//
+// Liveness / dirty bitmasks and cluster sizes live in LDS; the chain lives in global memory with its
+// top 256 entries mirrored in LDS.
+#include "hicmi_internal.h"
+
+namespace hicmi {
+
+static constexpr int NN_THREADS = 1024;
+static constexpr int NN_DMAX = 1024;                     // at most one dirty entry per lane
+
+struct ArgMin { double v; int i; };
+
+__device__ __forceinline__ ArgMin argmin_wave(ArgMin a)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double ov = __shfl_xor(a.v, off, 64);
+        int oi = __shfl_xor(a.i, off, 64);
+        if (ov < a.v || (ov == a.v && oi < a.i)) { a.v = ov; a.i = oi; }
+    }
+    return a;
+}
+
+// workspace layout (all 16-byte aligned)
+struct NNWorkspace {
+    int* state;                 // [0] step [1] len [2] top [3] second [4] first_ptr [5] stop [6] n_dirty
+    unsigned long long* prof;   // 6 phase totals
+    uint32_t* alive;            // nwords
+    uint16_t* size;             // n
+    int* gtime;                 // n: dirty time stamp of a slot in the finished epoch, -1 = clean
+    int* dslot;                 // NN_DMAX
+    int* dtime;                 // NN_DMAX
+};
+
+static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+size_t nnchain_workspace_bytes(int n)
+{
+    size_t nwords = (size_t)(n + 31) / 32;
+    return 256 + align16(nwords * 4) + align16((size_t)n * 2) + align16((size_t)n * 4) + 2 * align16(NN_DMAX * 4);
+}
+
+static NNWorkspace carve(void* ws, int n)
+{
+    unsigned char* p = reinterpret_cast<unsigned char*>(ws);
+    size_t nwords = (size_t)(n + 31) / 32;
+    NNWorkspace w;
+    w.state = reinterpret_cast<int*>(p);
+    w.prof = reinterpret_cast<unsigned long long*>(p + 64);
+    p += 256;
+    w.alive = reinterpret_cast<uint32_t*>(p); p += align16(nwords * 4);
+    w.size = reinterpret_cast<uint16_t*>(p); p += align16((size_t)n * 2);
+    w.gtime = reinterpret_cast<int*>(p); p += align16((size_t)n * 4);
+    w.dslot = reinterpret_cast<int*>(p); p += align16(NN_DMAX * 4);
+    w.dtime = reinterpret_cast<int*>(p);
+    return w;
+}
+
+__global__ __launch_bounds__(256) void k_nn_init(NNWorkspace w, int n)
+{
+    const int nwords = (n + 31) >> 5;
+    const int gid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    for (int i = gid; i < nwords; i += stride) {
+        int rem = n - i * 32;
+        w.alive[i] = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+    }
+    for (int i = gid; i < n; i += stride) { w.size[i] = 1; w.gtime[i] = -1; }
+    if (gid < 16) w.state[gid] = 0;
+    if (gid < 8) w.prof[gid] = 0ull;
+}
+
+// PROFILE adds wall-clock stamps (100 MHz) around the phases, accumulated in w.prof[0..4] =
+// {chain bookkeeping, row scan, pick neighbour, merge bookkeeping, Lance-Williams update}.
+template <bool PROFILE>
+__global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W, int64_t ld, int n,
+                                                         int* __restrict__ chain, double* __restrict__ zraw,
+                                                         NNWorkspace w, int dcap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_nn[];
+    const int nwords = (n + 31) >> 5, nw4 = (nwords + 3) & ~3;
+    uint32_t* alive = reinterpret_cast<uint32_t*>(smem_nn);
+    uint32_t* dmask = alive + nw4;
+    uint16_t* lsize = reinterpret_cast<uint16_t*>(dmask + nw4);
+    __shared__ int dslot[NN_DMAX], dtime[NN_DMAX];
+    __shared__ double s_v[16];
+    __shared__ int s_i[16];
+    __shared__ int ring[256];
+    __shared__ double s_dprev;
+    __shared__ int s_x, s_prev, s_done, s_stop, s_mx, s_my, s_nx, s_ny, s_tx, s_ty, s_ey;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int step = w.state[0];
+    if (step >= n - 1 || w.state[5]) {                     // finished (or stopped) in an earlier epoch
+        if (tid == 0) w.state[6] = 0;
+        return;
+    }
+    for (int i = tid; i < nwords; i += NN_THREADS) { alive[i] = w.alive[i]; dmask[i] = 0u; }
+    for (int i = tid; i < n; i += NN_THREADS) { lsize[i] = w.size[i]; w.gtime[i] = -1; }
+    // lane-0 private chain state
+    int len = w.state[1], top = w.state[2], second = w.state[3], first_ptr = w.state[4], ring_lo = len;
+    unsigned long long t_book = 0, t_scan = 0, t_pick = 0, t_merge = 0, t_upd = 0, t0 = 0, t1 = 0;
+    if (tid == 0) { s_stop = 0; s_done = 0; }
+    __syncthreads();
+    int D = 0;                                              // dirty entries (uniform across lanes)
+
+    for (; step < n - 1 && D < dcap; step++) {
+        if (PROFILE && tid == 0) t0 = wall_clock64();
+        if (tid == 0 && len == 0) {
+            while (first_ptr < n && !((alive[first_ptr >> 5] >> (first_ptr & 31)) & 1u)) first_ptr++;
+            chain[0] = first_ptr; ring[0] = first_ptr; ring_lo = 0; top = first_ptr; second = -1; len = 1;
+        }
+        int guard = 0;
+        double cur = 0.0;
+        int ybest = -1;
+        while (true) {
+            if (tid == 0) { s_x = top; s_prev = (len > 1) ? second : -1; s_tx = -1; }
+            __syncthreads();
+            const int x = s_x, prev = s_prev;
+            if (tid < D && dslot[tid] == x) s_tx = dtime[tid];       // is the row itself dirty, and since when
+            __syncthreads();
+            if (PROFILE && tid == 0) { t1 = wall_clock64(); t_book += t1 - t0; t0 = t1; }
+            const int tx = s_tx;
+            const double* __restrict__ rowx = W + (int64_t)x * ld;
+            ArgMin best = {__builtin_inf(), 0x7fffffff};
+            // dirty partners: the value comes from whichever row was rewritten last
+            if (tid < D) {
+                const int d = dslot[tid];
+                if (d >= 0 && d != x && ((alive[d >> 5] >> (d & 31)) & 1u)) {
+                    const double v = dtime[tid] > tx ? W[(int64_t)d * ld + x] : rowx[d];
+                    best.v = v; best.i = d;
+                    if (d == prev) s_dprev = v;
+                }
+            }
+#pragma unroll 4
+            for (int j = tid * 2; j < n; j += 2 * NN_THREADS) {
+                double2 v = *reinterpret_cast<const double2*>(rowx + j);
+                uint32_t bits = (alive[j >> 5] & ~dmask[j >> 5]) >> (j & 31);     // j even: both bits in one word
+                if ((bits & 1u) && j != x && (v.x < best.v || (v.x == best.v && j < best.i))) { best.v = v.x; best.i = j; }
+                if ((bits & 2u) && j + 1 != x && j + 1 < n && (v.y < best.v || (v.y == best.v && j + 1 < best.i))) {
+                    best.v = v.y; best.i = j + 1;
+                }
+                if ((prev | 1) == (j | 1) && prev >= 0 && !((dmask[prev >> 5] >> (prev & 31)) & 1u))
+                    s_dprev = (prev & 1) ? v.y : v.x;                              // d(x, previous chain element)
+            }
+            best = argmin_wave(best);
+            if (lane == 0) { s_v[wave] = best.v; s_i[wave] = best.i; }
+            __syncthreads();
+            if (PROFILE && tid == 0) { t1 = wall_clock64(); t_scan += t1 - t0; t0 = t1; }
+            if (wave == 0) {
+                ArgMin m = {lane < 16 ? s_v[lane] : __builtin_inf(), lane < 16 ? s_i[lane] : 0x7fffffff};
+                m = argmin_wave(m);
+                if (lane == 0) {
+                    int y; double c;
+                    if (prev >= 0) {
+                        double dprev = s_dprev;
+                        if (m.v < dprev) { y = m.i; c = m.v; } else { y = prev; c = dprev; }
+                    } else { y = m.i; c = m.v; }
+                    int done = (prev >= 0 && y == prev);
+                    if (y < 0 || y >= n || ++guard > n + 2) { s_stop = 1; done = 1; }
+                    else if (!done) {
+                        chain[len] = y; ring[len & 255] = y;
+                        if (len - 255 > ring_lo) ring_lo = len - 255;
+                        second = top; top = y; len++;
+                    }
+                    cur = c; ybest = y;
+                    s_done = done;
+                }
+            }
+            __syncthreads();
+            if (PROFILE && tid == 0) { t1 = wall_clock64(); t_pick += t1 - t0; t0 = t1; }
+            if (s_done) break;
+        }
+        if (s_stop) break;
+        if (tid == 0) {
+            int xx = s_x, yy = ybest;
+            len -= 2;
+            if (xx > yy) { int t = xx; xx = yy; yy = t; }
+            int nx = lsize[xx], ny = lsize[yy];
+            zraw[4 * (int64_t)step + 0] = (double)xx;
+            zraw[4 * (int64_t)step + 1] = (double)yy;
+            zraw[4 * (int64_t)step + 2] = cur;
+            zraw[4 * (int64_t)step + 3] = (double)(nx + ny);
+            lsize[xx] = 0;
+            lsize[yy] = (uint16_t)(nx + ny);
+            alive[xx >> 5] &= ~(1u << (xx & 31));
+            s_mx = xx; s_my = yy; s_nx = nx; s_ny = ny; s_tx = -1; s_ty = -1; s_ey = -1;
+            top = len >= 1 ? (len - 1 >= ring_lo ? ring[(len - 1) & 255] : chain[len - 1]) : -1;
+            second = len >= 2 ? (len - 2 >= ring_lo ? ring[(len - 2) & 255] : chain[len - 2]) : -1;
+        }
+        __syncthreads();
+        const int mx = s_mx, my = s_my;
+        if (tid < D) {
+            if (dslot[tid] == mx) s_tx = dtime[tid];
+            if (dslot[tid] == my) { s_ty = dtime[tid]; s_ey = tid; }
+        }
+        __syncthreads();
+        if (PROFILE && tid == 0) { t1 = wall_clock64(); t_merge += t1 - t0; t0 = t1; }
+        {
+            const int tmx = s_tx, tmy = s_ty;
+            const double fx = (double)s_nx, fy = (double)s_ny, fs = (double)(s_nx + s_ny);
+            const double* __restrict__ rx = W + (int64_t)mx * ld;
+            double* __restrict__ ry = W + (int64_t)my * ld;
+            // dirty partners first (their loads overlap the streaming pass); results are stored after
+            // the streaming pass has rewritten row y
+            double dv = 0.0; int dd = -1;
+            if (tid < D) {
+                const int d = dslot[tid];
+                if (d >= 0 && d != my && ((alive[d >> 5] >> (d & 31)) & 1u)) {
+                    const double dxi = dtime[tid] > tmx ? W[(int64_t)d * ld + mx] : rx[d];
+                    const double dyi = dtime[tid] > tmy ? W[(int64_t)d * ld + my] : ry[d];
+                    dv = (fx * dxi + fy * dyi) / fs;
+                    dd = d;
+                }
+            }
+#pragma unroll 2
+            for (int j = tid * 2; j < n; j += 2 * NN_THREADS) {
+                double2 a = *reinterpret_cast<const double2*>(rx + j);
+                double2 b = *reinterpret_cast<const double2*>(ry + j);
+                uint32_t bits = (alive[j >> 5] & ~dmask[j >> 5]) >> (j & 31);
+                if ((bits & 1u) && j != my) b.x = (fx * a.x + fy * b.x) / fs;
+                if ((bits & 2u) && j + 1 != my && j + 1 < n) b.y = (fx * a.y + fy * b.y) / fs;
+                *reinterpret_cast<double2*>(ry + j) = b;
+            }
+            __syncthreads();
+            if (dd >= 0) ry[dd] = dv;
+            if (tid == 0) {                                 // cluster y is dirty from now on
+                if (s_ey >= 0) dslot[s_ey] = -1;            // its older entry is superseded
+                dslot[D] = my; dtime[D] = step;
+                dmask[my >> 5] |= 1u << (my & 31);
+            }
+            D++;
+        }
+        __syncthreads();
+        if (PROFILE && tid == 0) { t1 = wall_clock64(); t_upd += t1 - t0; }
+    }
+    // ---- save state for the flush kernel and the next epoch
+    __syncthreads();
+    for (int i = tid; i < nwords; i += NN_THREADS) w.alive[i] = alive[i];
+    for (int i = tid; i < n; i += NN_THREADS) w.size[i] = lsize[i];
+    if (tid < D) {
+        w.dslot[tid] = dslot[tid]; w.dtime[tid] = dtime[tid];
+        if (dslot[tid] >= 0) w.gtime[dslot[tid]] = dtime[tid];
+    }
+    if (tid == 0) {
+        w.state[0] = step; w.state[1] = len; w.state[2] = top; w.state[3] = second; w.state[4] = first_ptr;
+        w.state[5] = s_stop; w.state[6] = D;
+        if (PROFILE) { w.prof[0] += t_book; w.prof[1] += t_scan; w.prof[2] += t_pick; w.prof[3] += t_merge; w.prof[4] += t_upd; }
+    }
+}
+
+// Full-chip flush of the deferred column writes: for every dirty cluster d (time td) and every live
+// row i that did not merge after td, W[i][d] = W[d][i].  Reads are coalesced along row d.
+__global__ __launch_bounds__(256) void k_nn_flush(double* __restrict__ W, int64_t ld, int n, NNWorkspace w)
+{
+    const int e = blockIdx.y;
+    if (e >= w.state[6]) return;
+    const int d = w.dslot[e];
+    if (d < 0 || !((w.alive[d >> 5] >> (d & 31)) & 1u)) return;
+    const int td = w.dtime[e];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || i == d) return;
+    if (!((w.alive[i >> 5] >> (i & 31)) & 1u)) return;
+    if (w.gtime[i] > td) return;                           // row i is the authoritative one for this pair
+    W[(int64_t)i * ld + d] = W[(int64_t)d * ld + i];
+}
+
+void launch_nnchain(double* W, int64_t ldw, int n, int* chain, double* zraw, void* workspace, bool profile, int dcap,
+                    hipStream_t s)
+{
+    NNWorkspace w = carve(workspace, n);
+    if (dcap < 1) dcap = 1;
+    if (dcap > NN_DMAX) dcap = NN_DMAX;
+    hipLaunchKernelGGL(k_nn_init, dim3(64), dim3(256), 0, s, w, n);
+    const int nwords = (n + 31) / 32, nw4 = (nwords + 3) & ~3;
+    size_t lds = align16((size_t)nw4 * 8 + (size_t)n * 2);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int epochs = (n - 1 + dcap - 1) / dcap + 1;
+    for (int e = 0; e < epochs; e++) {
+        if (profile) hipLaunchKernelGGL(k_nn_epoch<true>, dim3(1), dim3(NN_THREADS), lds, s, W, ldw, n, chain, zraw, w, dcap);
+        else hipLaunchKernelGGL(k_nn_epoch<false>, dim3(1), dim3(NN_THREADS), lds, s, W, ldw, n, chain, zraw, w, dcap);
+        hipLaunchKernelGGL(k_nn_flush, dim3((n + 255) / 256, dcap), dim3(256), 0, s, W, ldw, n, w);
+    }
+}
+
+// status word and phase profile live at the start of the workspace
+const int* nnchain_state_ptr(void* workspace) { return reinterpret_cast<const int*>(workspace); }
+const unsigned long long* nnchain_prof_ptr(void* workspace)
+{
+    return reinterpret_cast<const unsigned long long*>(reinterpret_cast<unsigned char*>(workspace) + 64);
+}
+
+}  // namespace hicmi

@@ -141,178 +141,6 @@ void launch_build_w(const double* C, int64_t ldc, const double* np_sum, int n, d
 }
 
 // =================================================================================================
-// UPGMA by nearest-neighbour chain - SciPy's _hierarchy.nn_chain for method='average'
-// (scaffoldToChromosomes.py:197; algorithm restated in SURVEY.md A3 and oracle/oracle_c.c).
-//
-// The algorithm is a chain of ~3(n-1) DEPENDENT O(n) steps, each far too small to amortise a
-// grid-wide barrier (a 32k-bin row is 256 KB; an XCD-hierarchical grid barrier costs ~5 us, about
-// what one CU needs to stream the row), so it runs as ONE persistent 1024-lane workgroup:
-//   scan  : lanes stream row x of W with 16-byte loads, keep (min, lowest index) per lane,
-//           wave-shuffle reduce, 16-wave LDS reduce; strict '<' + index order == SciPy's tie rule,
-//           and the previous chain element is preferred exactly as SciPy does;
-//   merge : Lance-Williams (nx*d_xi + ny*d_yi)/(nx+ny) with five separate fp64 roundings, row y
-//           rewritten with coalesced stores and column y scattered so W stays symmetric.
-// Liveness (bitmask) and cluster sizes live in LDS; the chain lives in global memory with its top
-// 256 entries mirrored in LDS (lane 0 only).
-struct ArgMin { double v; int i; };
-
-__device__ __forceinline__ ArgMin argmin_wave(ArgMin a)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double ov = __shfl_xor(a.v, off, 64);
-        int oi = __shfl_xor(a.i, off, 64);
-        if (ov < a.v || (ov == a.v && oi < a.i)) { a.v = ov; a.i = oi; }
-    }
-    return a;
-}
-
-// PROFILE = true adds wall-clock stamps (100 MHz) around the phases; lane 0 writes the totals to
-// prof[0..4] = {chain bookkeeping, row scan, pick neighbour, merge bookkeeping, Lance-Williams update}.
-template <bool PROFILE>
-__global__ __launch_bounds__(1024) void k_nnchain(double* __restrict__ W, int64_t ld, int n, int* __restrict__ chain,
-                                                  double* __restrict__ zraw, int* __restrict__ status,
-                                                  unsigned long long* __restrict__ prof)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_nn[];
-    uint32_t* alive = reinterpret_cast<uint32_t*>(smem_nn);
-    const int nwords = (n + 31) >> 5;
-    uint16_t* lsize = reinterpret_cast<uint16_t*>(alive + ((nwords + 3) & ~3));   // cluster sizes (<= 65535 until the last merge)
-    __shared__ double s_v[16];
-    __shared__ int s_i[16];
-    __shared__ int ring[256];                            // top of the chain (chain[i] lives at ring[i & 255])
-    __shared__ double s_dprev;
-    __shared__ int s_x, s_prev, s_done, s_stop, s_mx, s_my, s_nx, s_ny;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int w = tid; w < nwords; w += 1024) {
-        int rem = n - w * 32;
-        alive[w] = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
-    }
-    for (int i = tid; i < n; i += 1024) lsize[i] = 1;
-    if (tid == 0) { s_stop = 0; s_done = 0; }
-    // lane-0 private chain state
-    int len = 0, top = -1, second = -1, first_ptr = 0, ring_lo = 0;
-    unsigned long long t_book = 0, t_scan = 0, t_pick = 0, t_merge = 0, t_upd = 0, t0 = 0, t1 = 0;
-    __syncthreads();
-
-    for (int step = 0; step < n - 1; step++) {
-        if (PROFILE && tid == 0) t0 = wall_clock64();
-        if (tid == 0 && len == 0) {
-            while (first_ptr < n && !((alive[first_ptr >> 5] >> (first_ptr & 31)) & 1u)) first_ptr++;
-            chain[0] = first_ptr; ring[0] = first_ptr; ring_lo = 0; top = first_ptr; second = -1; len = 1;
-        }
-        int guard = 0;
-        double cur = 0.0;
-        int ybest = -1;
-        while (true) {
-            if (tid == 0) { s_x = top; s_prev = (len > 1) ? second : -1; }
-            __syncthreads();
-            if (PROFILE && tid == 0) { t1 = wall_clock64(); t_book += t1 - t0; t0 = t1; }
-            const int x = s_x, prev = s_prev;
-            const double* __restrict__ rowx = W + (int64_t)x * ld;
-            ArgMin best = {__builtin_inf(), 0x7fffffff};
-#pragma unroll 4
-            for (int j = tid * 2; j < n; j += 2048) {
-                double2 v = *reinterpret_cast<const double2*>(rowx + j);
-                uint32_t bits = alive[j >> 5] >> (j & 31);          // j is even: both bits in one word
-                if ((bits & 1u) && j != x && v.x < best.v) { best.v = v.x; best.i = j; }
-                if ((bits & 2u) && j + 1 != x && j + 1 < n && v.y < best.v) { best.v = v.y; best.i = j + 1; }
-                if ((prev | 1) == (j | 1) && prev >= 0) s_dprev = (prev & 1) ? v.y : v.x;   // d(x, previous chain element)
-            }
-            best = argmin_wave(best);
-            if (lane == 0) { s_v[wave] = best.v; s_i[wave] = best.i; }
-            __syncthreads();
-            if (PROFILE && tid == 0) { t1 = wall_clock64(); t_scan += t1 - t0; t0 = t1; }
-            if (tid == 0) {
-                ArgMin m = {s_v[0], s_i[0]};
-                for (int w = 1; w < 16; w++)
-                    if (s_v[w] < m.v || (s_v[w] == m.v && s_i[w] < m.i)) { m.v = s_v[w]; m.i = s_i[w]; }
-                int y; double c;
-                if (prev >= 0) {
-                    double dprev = s_dprev;
-                    if (m.v < dprev) { y = m.i; c = m.v; } else { y = prev; c = dprev; }
-                } else { y = m.i; c = m.v; }
-                int done = (prev >= 0 && y == prev);
-                if (y < 0 || y >= n || ++guard > n + 2) { s_stop = 1; done = 1; }
-                else if (!done) {
-                    chain[len] = y; ring[len & 255] = y;
-                    if (len - 255 > ring_lo) ring_lo = len - 255;
-                    second = top; top = y; len++;
-                }
-                cur = c; ybest = y;
-                s_done = done;
-            }
-            __syncthreads();
-            if (PROFILE && tid == 0) { t1 = wall_clock64(); t_pick += t1 - t0; t0 = t1; }
-            if (s_done) break;
-        }
-        if (s_stop) break;
-        if (tid == 0) {
-            int xx = s_x, yy = ybest;
-            len -= 2;
-            if (xx > yy) { int t = xx; xx = yy; yy = t; }
-            int nx = lsize[xx], ny = lsize[yy];
-            zraw[4 * step + 0] = (double)xx;
-            zraw[4 * step + 1] = (double)yy;
-            zraw[4 * step + 2] = cur;
-            zraw[4 * step + 3] = (double)(nx + ny);
-            lsize[xx] = 0;
-            lsize[yy] = (uint16_t)(nx + ny);
-            alive[xx >> 5] &= ~(1u << (xx & 31));
-            s_mx = xx; s_my = yy; s_nx = nx; s_ny = ny;
-            top = len >= 1 ? (len - 1 >= ring_lo ? ring[(len - 1) & 255] : chain[len - 1]) : -1;
-            second = len >= 2 ? (len - 2 >= ring_lo ? ring[(len - 2) & 255] : chain[len - 2]) : -1;
-        }
-        __syncthreads();
-        if (PROFILE && tid == 0) { t1 = wall_clock64(); t_merge += t1 - t0; t0 = t1; }
-        {
-            const int mx = s_mx, my = s_my;
-            const double fx = (double)s_nx, fy = (double)s_ny, fs = (double)(s_nx + s_ny);
-            const double* __restrict__ rx = W + (int64_t)mx * ld;
-            double* __restrict__ ry = W + (int64_t)my * ld;
-#pragma unroll 2
-            for (int j = tid * 2; j < n; j += 2048) {
-                double2 a = *reinterpret_cast<const double2*>(rx + j);
-                double2 b = *reinterpret_cast<const double2*>(ry + j);
-                uint32_t bits = alive[j >> 5] >> (j & 31);
-                if ((bits & 1u) && j != my) {
-                    double v = (fx * a.x + fy * b.x) / fs;
-                    b.x = v;
-                    W[(int64_t)j * ld + my] = v;
-                }
-                if ((bits & 2u) && j + 1 != my && j + 1 < n) {
-                    double v = (fx * a.y + fy * b.y) / fs;
-                    b.y = v;
-                    W[(int64_t)(j + 1) * ld + my] = v;
-                }
-                *reinterpret_cast<double2*>(ry + j) = b;
-            }
-        }
-        __syncthreads();
-        if (PROFILE && tid == 0) { t1 = wall_clock64(); t_upd += t1 - t0; }
-    }
-    if (tid == 0) {
-        status[0] = s_stop;
-        if (PROFILE) { prof[0] = t_book; prof[1] = t_scan; prof[2] = t_pick; prof[3] = t_merge; prof[4] = t_upd; }
-    }
-}
-
-void launch_nnchain(double* W, int64_t ldw, int n, int* chain, double* zraw, int* status, unsigned long long* prof,
-                    hipStream_t s)
-{
-    size_t lds = sizeof(uint32_t) * (size_t)((((n + 31) / 32) + 3) & ~3) + sizeof(uint16_t) * (size_t)n;
-    lds = (lds + 15) & ~(size_t)15;
-    if (prof) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nnchain<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_nnchain<true>, dim3(1), dim3(1024), lds, s, W, ldw, n, chain, zraw, status, prof);
-    } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nnchain<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_nnchain<false>, dim3(1), dim3(1024), lds, s, W, ldw, n, chain, zraw, status, prof);
-    }
-}
-
-// =================================================================================================
 // Cut-scan counts.  With rank[i][j] = position of column j in row i's descending similarity order,
 //   #{ v in R[i][0:L] : lo <= v <= hi }  ==  #{ j in [lo, hi] : rank[i][j] < L }
 // so every query of scaffoldToChromosomes.py:455-459 (mode 0: hi = i, L = i - lo) and :631

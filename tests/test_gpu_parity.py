@@ -80,6 +80,25 @@ def test_upgma_random_bit_exact(hic, orc, n, seed):
     assert np.array_equal(leaves, leaves_o)
 
 
+@pytest.mark.parametrize("dcap", [1, 2, 7, 64])
+@pytest.mark.parametrize("n,seed", [(5, 0), (65, 4), (333, 5), (1025, 6)])
+def test_upgma_deferred_columns_any_flush_period(hic, orc, monkeypatch, n, seed, dcap):
+    """The nn-chain kernel defers the column half of each update and flushes every DCAP merges
+    (k_nnchain.hip); results must not depend on DCAP."""
+    monkeypatch.setenv("HICMI_NNCHAIN_DCAP", str(dcap))
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, n)) + 0.01
+    c = c + c.T
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, c)
+    assert np.array_equal(zraw, zraw_o)
+    assert np.array_equal(leaves, leaves_o)
+    ties = rng.integers(1, 4, size=(n, n)).astype(np.float64)
+    ties = np.triu(ties, 1) + np.triu(ties, 1).T + np.eye(n)
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, ties)
+    assert np.array_equal(zraw, zraw_o)
+    assert np.array_equal(leaves, leaves_o)
+
+
 def test_upgma_heavy_ties_bit_exact(hic, orc):
     rng = np.random.default_rng(11)
     c = rng.integers(1, 4, size=(200, 200)).astype(np.float64)
