@@ -84,16 +84,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    import numpy as np
     import torch
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from hic_genome_assembler_amd import _lib, synth
+    from hic_genome_assembler_amd import _lib, dist, synth
+    dist.init("nccl", device=dev)                       # RCCL; no-op for one process
     from hic_genome_assembler_amd import orderGenome as p2, scaffoldToChromosomes as p1
     from hic_genome_assembler_amd.hostio import Bin
 
@@ -107,13 +103,14 @@ def main():
     f = lambda k: os.path.join(work, k)  # noqa: E731
     ctx = _lib.Context(local)
     last = {}
+    bin_objects = make_bins(lay, Bin)                   # the .bed metadata, parsed once like the matrix
 
     def step():
         ctx.set_contacts_device(contacts.data_ptr(), n, keepalive=contacts)
         dm = p1.DeviceMatrix(ctx)
         with contextlib.redirect_stdout(io.StringIO()):
             ta = time.perf_counter()
-            cuts = p1.runResident(dm, make_bins(lay, Bin), sizes, f("dendrogramOrder.txt"), f("binGroups.txt"),
+            cuts = p1.runResident(dm, list(bin_objects), sizes, f("dendrogramOrder.txt"), f("binGroups.txt"),
                                   f("assessment.txt"), f("chromosomeGroups.txt"), 5, 0.0, .05)
             last["part1_s"] = time.perf_counter() - ta
             if not args.part1_only:
@@ -123,9 +120,7 @@ def main():
         last["part2_s"] = time.perf_counter() - ta - last["part1_s"]
         last["cuts"] = cuts
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = dist.barrier
 
     for _ in range(args.warmup):
         step()
@@ -140,11 +135,7 @@ def main():
     ctx.synchronize()
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0, device=dev)
     timing = ctx.timing()
     ctx.timing_enable(False)
 
@@ -190,7 +181,7 @@ def main():
     shutil.rmtree(work, ignore_errors=True)
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
