@@ -27,7 +27,6 @@ namespace hicmi {
 
 static constexpr int NN_THREADS = 1024;
 static constexpr int NN_DMAX = 1024;                     // at most one dirty entry per lane
-static constexpr int NN_PRE = 8;                         // 16-byte loads per lane kept in registers (covers n <= 16384)
 
 struct ArgMin { double v; int i; };
 
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
     __shared__ int s_i[16];
     __shared__ int ring[256];
     __shared__ double s_dprev;
-    __shared__ int s_x, s_prev, s_done, s_stop, s_mx, s_my, s_nx, s_ny, s_tx, s_ty, s_ey, s_next;
+    __shared__ int s_x, s_prev, s_done, s_stop, s_mx, s_my, s_nx, s_ny, s_tx, s_ty, s_ey;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int step = w.state[0];
@@ -123,10 +122,6 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
     if (tid == 0) { s_stop = 0; s_done = 0; }
     __syncthreads();
     int D = 0;                                              // dirty entries (uniform across lanes)
-    double2 pre[NN_PRE];                                    // next scan row, loaded while the update runs
-    int pre_row = -1;
-#pragma unroll
-    for (int k = 0; k < NN_PRE; k++) pre[k] = make_double2(0.0, 0.0);
 
     for (; step < n - 1 && D < dcap; step++) {
         if (PROFILE && tid == 0) t0 = wall_clock64();
@@ -156,30 +151,17 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
                     if (d == prev) s_dprev = v;
                 }
             }
-            const bool have_pre = (pre_row == x);            // row x was prefetched during the last update
-#pragma unroll
-            for (int k = 0; k < NN_PRE; k++) {
-                const int j = tid * 2 + k * 2 * NN_THREADS;
-                if (j < n && !have_pre) pre[k] = *reinterpret_cast<const double2*>(rowx + j);
-            }
-            pre_row = -1;
-            const bool prev_clean = prev >= 0 && !((dmask[prev >> 5] >> (prev & 31)) & 1u);
-            auto visit = [&](const double2 v, const int j) {
+#pragma unroll 4
+            for (int j = tid * 2; j < n; j += 2 * NN_THREADS) {
+                double2 v = *reinterpret_cast<const double2*>(rowx + j);
                 uint32_t bits = (alive[j >> 5] & ~dmask[j >> 5]) >> (j & 31);     // j even: both bits in one word
                 if ((bits & 1u) && j != x && (v.x < best.v || (v.x == best.v && j < best.i))) { best.v = v.x; best.i = j; }
                 if ((bits & 2u) && j + 1 != x && j + 1 < n && (v.y < best.v || (v.y == best.v && j + 1 < best.i))) {
                     best.v = v.y; best.i = j + 1;
                 }
-                if (prev_clean && (prev | 1) == (j | 1)) s_dprev = (prev & 1) ? v.y : v.x;   // d(x, previous chain element)
-            };
-#pragma unroll
-            for (int k = 0; k < NN_PRE; k++) {
-                const int j = tid * 2 + k * 2 * NN_THREADS;
-                if (j < n) visit(pre[k], j);
+                if ((prev | 1) == (j | 1) && prev >= 0 && !((dmask[prev >> 5] >> (prev & 31)) & 1u))
+                    s_dprev = (prev & 1) ? v.y : v.x;                              // d(x, previous chain element)
             }
-#pragma unroll 4
-            for (int j = tid * 2 + NN_PRE * 2 * NN_THREADS; j < n; j += 2 * NN_THREADS)
-                visit(*reinterpret_cast<const double2*>(rowx + j), j);
             best = argmin_wave(best);
             if (lane == 0) { s_v[wave] = best.v; s_i[wave] = best.i; }
             __syncthreads();
@@ -224,24 +206,9 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
             s_mx = xx; s_my = yy; s_nx = nx; s_ny = ny; s_tx = -1; s_ty = -1; s_ey = -1;
             top = len >= 1 ? (len - 1 >= ring_lo ? ring[(len - 1) & 255] : chain[len - 1]) : -1;
             second = len >= 2 ? (len - 2 >= ring_lo ? ring[(len - 2) & 255] : chain[len - 2]) : -1;
-            s_next = top;                                   // the row the next scan will read (-1: chain is empty)
         }
         __syncthreads();
         const int mx = s_mx, my = s_my;
-        {
-            // the next scan row is not touched by this update (only row y is rewritten, and y has left
-            // the chain), so its loads are issued now and complete under the update
-            const int nxt = s_next;
-            if (nxt >= 0) {
-                const double* __restrict__ rown = W + (int64_t)nxt * ld;
-#pragma unroll
-                for (int k = 0; k < NN_PRE; k++) {
-                    const int j = tid * 2 + k * 2 * NN_THREADS;
-                    if (j < n) pre[k] = *reinterpret_cast<const double2*>(rown + j);
-                }
-            }
-            pre_row = nxt;
-        }
         if (tid < D) {
             if (dslot[tid] == mx) s_tx = dtime[tid];
             if (dslot[tid] == my) { s_ty = dtime[tid]; s_ey = tid; }
