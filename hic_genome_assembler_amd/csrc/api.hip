@@ -56,7 +56,7 @@ struct hicmi_ctx {
     double *d_np = nullptr, *d_seq = nullptr;
     bool have_sums = false;
     // upgma
-    double* dW = nullptr; int64_t ldw = 0; int64_t w_rows = 0;
+    double *dW = nullptr, *dW2 = nullptr; int64_t ldw = 0; int64_t w_rows = 0;
     int *d_size = nullptr, *d_chain = nullptr, *d_status = nullptr;
     double* d_zraw = nullptr;
     std::vector<double> zraw;
@@ -219,7 +219,7 @@ int hicmi_destroy(hicmi_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     drop_matrix_state(c);
-    free_dev(c->dW); free_dev(c->d_size); free_dev(c->d_chain); free_dev(c->d_status); free_dev(c->d_zraw);
+    free_dev(c->dW); free_dev(c->dW2); free_dev(c->d_size); free_dev(c->d_chain); free_dev(c->d_status); free_dev(c->d_zraw);
     free_dev(c->d_order); free_dev(c->dR); free_dev(c->dRank); free_dev(c->d_sort_scratch);
     free_dev(c->d_x); free_dev(c->d_sig); free_dev(c->d_tmp);
     free_dev(c->dM2); free_dev(c->d_sel); free_dev(c->d_H); free_dev(c->d_perms); free_dev(c->d_scores);
@@ -381,8 +381,9 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
     if (n == 1) { leaves_out[0] = 0; c->zraw.clear(); return HICMI_OK; }
     const int64_t ldw = (n + 15) & ~(int64_t)15;
     if (c->w_rows < n || c->ldw != ldw || !c->dW) {
-        free_dev(c->dW); c->dW = nullptr;
+        free_dev(c->dW); free_dev(c->dW2); c->dW = c->dW2 = nullptr;
         HIPCHK(hipMalloc((void**)&c->dW, sizeof(double) * (size_t)n * (size_t)ldw));
+        HIPCHK(hipMalloc((void**)&c->dW2, sizeof(double) * (size_t)n * (size_t)ldw));
         c->ldw = ldw; c->w_rows = n;
         free_dev(c->d_size); free_dev(c->d_chain); free_dev(c->d_zraw); free_dev(c->d_status);
         c->d_size = c->d_chain = c->d_status = nullptr; c->d_zraw = nullptr;
@@ -401,8 +402,8 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         // one row write and one column write of 8-byte elements
         Timed t(c, F_NNCHAIN, 8.0 * 7.0 * (double)n * (double)(n - 1));
         const char* cap = getenv("HICMI_NNCHAIN_DCAP");           // merges between two column flushes (tests shrink it)
-        launch_nnchain(c->dW, ldw, (int)n, c->d_chain, c->d_zraw, c->d_size, getenv("HICMI_NNCHAIN_PROFILE") != nullptr,
-                       cap ? atoi(cap) : 1024, c->stream);
+        launch_nnchain(c->dW, c->dW2, ldw, (int)n, c->d_chain, c->d_zraw, c->d_size, getenv("HICMI_NNCHAIN_PROFILE") != nullptr,
+                       cap ? atoi(cap) : 1024, getenv("HICMI_NNCHAIN_NO_COMPACT") == nullptr, c->stream);
     }
     HIPCHK(hipGetLastError());
     int status = 0;

@@ -50,6 +50,9 @@ struct NNWorkspace {
     int* gtime;                 // n: dirty time stamp of a slot in the finished epoch, -1 = clean
     int* dslot;                 // NN_DMAX
     int* dtime;                 // NN_DMAX
+    int* orig;                  // n: original bin of each current slot (changes at every compaction)
+    int* newidx;                // n: scratch of the compaction (old slot -> new slot, -1 = dead)
+    int* oldidx;                // n: scratch of the compaction (new slot -> old slot)
 };
 
 static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -57,7 +60,7 @@ static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 size_t nnchain_workspace_bytes(int n)
 {
     size_t nwords = (size_t)(n + 31) / 32;
-    return 256 + align16(nwords * 4) + align16((size_t)n * 2) + align16((size_t)n * 4) + 2 * align16(NN_DMAX * 4);
+    return 256 + align16(nwords * 4) + align16((size_t)n * 2) + 4 * align16((size_t)n * 4) + 2 * align16(NN_DMAX * 4);
 }
 
 static NNWorkspace carve(void* ws, int n)
@@ -72,7 +75,10 @@ static NNWorkspace carve(void* ws, int n)
     w.size = reinterpret_cast<uint16_t*>(p); p += align16((size_t)n * 2);
     w.gtime = reinterpret_cast<int*>(p); p += align16((size_t)n * 4);
     w.dslot = reinterpret_cast<int*>(p); p += align16(NN_DMAX * 4);
-    w.dtime = reinterpret_cast<int*>(p);
+    w.dtime = reinterpret_cast<int*>(p); p += align16(NN_DMAX * 4);
+    w.orig = reinterpret_cast<int*>(p); p += align16((size_t)n * 4);
+    w.newidx = reinterpret_cast<int*>(p); p += align16((size_t)n * 4);
+    w.oldidx = reinterpret_cast<int*>(p);
     return w;
 }
 
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256) void k_nn_init(NNWorkspace w, int n)
         int rem = n - i * 32;
         w.alive[i] = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
     }
-    for (int i = gid; i < n; i += stride) { w.size[i] = 1; w.gtime[i] = -1; }
+    for (int i = gid; i < n; i += stride) { w.size[i] = 1; w.gtime[i] = -1; w.orig[i] = i; }
     if (gid < 16) w.state[gid] = 0;
     if (gid < 8) w.prof[gid] = 0ull;
 }
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(256) void k_nn_init(NNWorkspace w, int n)
 template <bool PROFILE>
 __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W, int64_t ld, int n,
                                                          int* __restrict__ chain, double* __restrict__ zraw,
-                                                         NNWorkspace w, int dcap)
+                                                         NNWorkspace w, int dcap, int total_steps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_nn[];
     const int nwords = (n + 31) >> 5, nw4 = (nwords + 3) & ~3;
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int step = w.state[0];
-    if (step >= n - 1 || w.state[5]) {                     // finished (or stopped) in an earlier epoch
+    if (step >= total_steps || w.state[5]) {               // finished (or stopped) in an earlier epoch
         if (tid == 0) w.state[6] = 0;
         return;
     }
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
     __syncthreads();
     int D = 0;                                              // dirty entries (uniform across lanes)
 
-    for (; step < n - 1 && D < dcap; step++) {
+    for (; step < total_steps && D < dcap; step++) {
         if (PROFILE && tid == 0) t0 = wall_clock64();
         if (tid == 0 && len == 0) {
             while (first_ptr < n && !((alive[first_ptr >> 5] >> (first_ptr & 31)) & 1u)) first_ptr++;
@@ -284,23 +290,131 @@ __global__ __launch_bounds__(256) void k_nn_flush(double* __restrict__ W, int64_
     W[(int64_t)i * ld + d] = W[(int64_t)d * ld + i];
 }
 
-void launch_nnchain(double* W, int64_t ldw, int n, int* chain, double* zraw, void* workspace, bool profile, int dcap,
-                    hipStream_t s)
+// ---- compaction ------------------------------------------------------------------------------------
+// Dead clusters still occupy columns of every row that is scanned.  When fewer than 3/4 of the
+// current slots are alive, the live rows/columns are copied (order preserved, so "lowest index wins"
+// ties are unaffected) into the other buffer by the whole chip, and the chain continues on the
+// smaller matrix.  Raw merges are recorded with current slot numbers and translated to original bins
+// at the end of every compaction interval.
+__global__ __launch_bounds__(1024) void k_nn_remap(NNWorkspace w, int n_cur, int* __restrict__ chain)
+{
+    __shared__ int wsum[1024];
+    __shared__ int s_total;
+    const int tid = threadIdx.x, nwords = (n_cur + 31) >> 5;
+    if (w.state[5]) return;
+    // exclusive prefix of the per-word popcounts (nwords <= 2048: two words per lane)
+    const int w0 = 2 * tid, w1 = 2 * tid + 1;
+    const uint32_t a0 = w0 < nwords ? w.alive[w0] : 0u, a1 = w1 < nwords ? w.alive[w1] : 0u;
+    const int c0 = __popc(a0), c1 = __popc(a1);
+    wsum[tid] = c0 + c1;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = tid >= off ? wsum[tid - off] : 0;
+        __syncthreads();
+        wsum[tid] += v;
+        __syncthreads();
+    }
+    const int base0 = wsum[tid] - (c0 + c1), base1 = base0 + c0;
+    if (tid == 1023) s_total = wsum[1023];
+    for (int b = 0; b < 32; b++) {
+        const int i0 = w0 * 32 + b, i1 = w1 * 32 + b;
+        if (i0 < n_cur) {
+            if ((a0 >> b) & 1u) { int nw = base0 + __popc(a0 & ((1u << b) - 1u)); w.newidx[i0] = nw; w.oldidx[nw] = i0; }
+            else w.newidx[i0] = -1;
+        }
+        if (i1 < n_cur) {
+            if ((a1 >> b) & 1u) { int nw = base1 + __popc(a1 & ((1u << b) - 1u)); w.newidx[i1] = nw; w.oldidx[nw] = i1; }
+            else w.newidx[i1] = -1;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int n_new = s_total;
+    // sizes / original bins move down in place: chunk by chunk, reads of a chunk finish before its writes,
+    // and a write never lands beyond the chunk being processed (new index <= old index)
+    for (int c0i = 0; c0i < n_cur; c0i += 1024) {
+        const int i = c0i + tid;
+        int nw = -1; uint16_t sz = 0; int og = 0;
+        if (i < n_cur) { nw = w.newidx[i]; sz = w.size[i]; og = w.orig[i]; }
+        __syncthreads();
+        if (nw >= 0) { w.size[nw] = sz; w.orig[nw] = og; }
+        __syncthreads();
+    }
+    const int len = w.state[1];
+    for (int i = tid; i < len; i += 1024) chain[i] = w.newidx[chain[i]];
+    const int nw_words = (n_new + 31) >> 5;
+    for (int i = tid; i < nw_words; i += 1024) {
+        int rem = n_new - i * 32;
+        w.alive[i] = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+    }
+    for (int i = tid; i < n_new; i += 1024) w.gtime[i] = -1;
+    __syncthreads();
+    if (tid == 0) {
+        if (w.state[2] >= 0) w.state[2] = w.newidx[w.state[2]];
+        if (w.state[3] >= 0) w.state[3] = w.newidx[w.state[3]];
+        w.state[4] = 0;                                  // every slot is alive again: the lowest live index is 0
+        w.state[7] = n_new;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nn_compact_copy(const double* __restrict__ src, double* __restrict__ dst,
+                                                         int64_t ld, NNWorkspace w, int n_new)
+{
+    if (w.state[5]) return;
+    const int r = blockIdx.x;
+    const double* __restrict__ srow = src + (int64_t)w.oldidx[r] * ld;
+    double* __restrict__ drow = dst + (int64_t)r * ld;
+    for (int c = threadIdx.x; c < n_new; c += 256) drow[c] = srow[w.oldidx[c]];
+    if (threadIdx.x == 0 && n_new < ld) drow[n_new] = __builtin_inf();
+}
+
+__global__ __launch_bounds__(256) void k_nn_translate(double* __restrict__ zraw, int s0, int s1, NNWorkspace w)
+{
+    const int s = s0 + blockIdx.x * 256 + threadIdx.x;
+    if (s >= s1 || s >= w.state[0]) return;
+    zraw[4 * (int64_t)s + 0] = (double)w.orig[(int)zraw[4 * (int64_t)s + 0]];
+    zraw[4 * (int64_t)s + 1] = (double)w.orig[(int)zraw[4 * (int64_t)s + 1]];
+}
+
+// W and W2: two n x ldw buffers (W holds the distances on entry; both are scratch afterwards).
+void launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double* zraw, void* workspace, bool profile,
+                    int dcap, bool compact, hipStream_t s)
 {
     NNWorkspace w = carve(workspace, n);
     if (dcap < 1) dcap = 1;
     if (dcap > NN_DMAX) dcap = NN_DMAX;
     hipLaunchKernelGGL(k_nn_init, dim3(64), dim3(256), 0, s, w, n);
-    const int nwords = (n + 31) / 32, nw4 = (nwords + 3) & ~3;
-    size_t lds = align16((size_t)nw4 * 8 + (size_t)n * 2);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int epochs = (n - 1 + dcap - 1) / dcap + 1;
-    for (int e = 0; e < epochs; e++) {
-        if (profile) hipLaunchKernelGGL(k_nn_epoch<true>, dim3(1), dim3(NN_THREADS), lds, s, W, ldw, n, chain, zraw, w, dcap);
-        else hipLaunchKernelGGL(k_nn_epoch<false>, dim3(1), dim3(NN_THREADS), lds, s, W, ldw, n, chain, zraw, w, dcap);
-        hipLaunchKernelGGL(k_nn_flush, dim3((n + 255) / 256, dcap), dim3(256), 0, s, W, ldw, n, w);
+    const int total_steps = n - 1;
+    int n_cur = n, done = 0, interval_start = 0;
+    double *cur = W, *other = W2;
+    {
+        const int nwords = (n + 31) / 32, nw4 = (nwords + 3) & ~3;
+        size_t lds_max = align16((size_t)nw4 * 8 + (size_t)n * 2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     }
+    while (done < total_steps) {
+        const int nwords = (n_cur + 31) / 32, nw4 = (nwords + 3) & ~3;
+        const size_t lds = align16((size_t)nw4 * 8 + (size_t)n_cur * 2);
+        if (profile) hipLaunchKernelGGL(k_nn_epoch<true>, dim3(1), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+        else hipLaunchKernelGGL(k_nn_epoch<false>, dim3(1), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+        const int did = total_steps - done < dcap ? total_steps - done : dcap;
+        done += did;
+        if (done >= total_steps) break;
+        hipLaunchKernelGGL(k_nn_flush, dim3((n_cur + 255) / 256, dcap), dim3(256), 0, s, cur, ldw, n_cur, w);
+        const int live = n - done;
+        if (compact && other && live >= 2 && (int64_t)live * 4 <= (int64_t)n_cur * 3) {
+            hipLaunchKernelGGL(k_nn_translate, dim3((done - interval_start + 255) / 256), dim3(256), 0, s, zraw, interval_start,
+                               done, w);
+            interval_start = done;
+            hipLaunchKernelGGL(k_nn_remap, dim3(1), dim3(1024), 0, s, w, n_cur, chain);
+            hipLaunchKernelGGL(k_nn_compact_copy, dim3(live), dim3(256), 0, s, cur, other, ldw, w, live);
+            double* t = cur; cur = other; other = t;
+            n_cur = live;
+        }
+    }
+    hipLaunchKernelGGL(k_nn_translate, dim3((total_steps - interval_start + 255) / 256), dim3(256), 0, s, zraw, interval_start,
+                       total_steps, w);
 }
 
 // status word and phase profile live at the start of the workspace
