@@ -59,6 +59,9 @@ SIGNATURES = {
     "hicmi_p2_decide_insertion": (ctypes.c_int, [_vp, _vp, _vp, c_i64, ctypes.c_int32, ctypes.c_int32,
                                                  ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_int32),
                                                  ctypes.POINTER(c_dbl)]),
+    "hicmi_p2_insert_all": (ctypes.c_int, [_vp, _vp, _vp, c_i64, _vp, c_i64, ctypes.POINTER(c_dbl)]),
+    "hicmi_p2_scan_pass": (ctypes.c_int, [_vp, _vp, _vp, c_i64, c_i64, c_dbl, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl),
+                                          ctypes.POINTER(ctypes.c_int32)]),
     "hicmi_timing_reset": (ctypes.c_int, [_vp]),
     "hicmi_timing_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "hicmi_timing_get": (ctypes.c_int, [_vp, ctypes.c_char_p, c_i64, _vp, _vp, _vp, c_i64, ctypes.POINTER(c_i64)]),
@@ -315,6 +318,29 @@ class Context:
         self._arr_sig = a.tobytes() + b.tobytes()
         self._arr_len = len(a)
         return gap.value, r.value, best.value
+
+    def p2_insert_all(self, ids, rev, new_ids):
+        """orderRemainderScaffolds in one call; returns (ids, rev, bestCost of the last insertion)."""
+        s0, k = len(ids), len(new_ids)
+        a = np.zeros(s0 + k, np.int32); a[:s0] = ids
+        b = np.zeros(s0 + k, np.uint8); b[:s0] = rev
+        nw = np.ascontiguousarray(new_ids, dtype=np.int32)
+        best = c_dbl()
+        _check(self._lib.hicmi_p2_insert_all(self._h, _ptr(a), _ptr(b), s0, _ptr(nw), k, ctypes.byref(best)))
+        self._arr_sig = None
+        return a, b, best.value
+
+    def p2_scan_pass(self, ids, rev, k, total, best, cur_fast):
+        """One round of scanOrdering; returns (ids, rev, best, cur_fast, improved)."""
+        a = np.ascontiguousarray(ids, dtype=np.int32).copy()
+        b = np.ascontiguousarray(rev, dtype=np.uint8).copy()
+        bst = c_dbl(float(best))
+        cf = c_dbl(float("nan") if cur_fast is None else float(cur_fast))
+        imp = ctypes.c_int32()
+        _check(self._lib.hicmi_p2_scan_pass(self._h, _ptr(a), _ptr(b), len(a), int(k), float(total), ctypes.byref(bst),
+                                            ctypes.byref(cf), ctypes.byref(imp)))
+        self._arr_sig = None
+        return a, b, bst.value, cf.value, bool(imp.value)
 
     # ---- misc
     def synchronize(self):

@@ -1070,6 +1070,61 @@ int hicmi_p2_decide_insertion(hicmi_ctx* c, const int32_t* ids, const uint8_t* r
     return HICMI_OK;
 }
 
+
+// Whole loops of the search, so that a chromosome costs a handful of host calls (several chromosomes
+// run concurrently from host threads, each on its own context).
+int hicmi_p2_insert_all(hicmi_ctx* c, int32_t* ids, uint8_t* rev, int64_t S0, const int32_t* new_ids, int64_t n_new,
+                        double* best_out)
+{
+    // orderRemainderScaffolds (OG:475-493) for n_new >= 1 scaffolds pulled in order: ids/rev hold S0 entries
+    // on entry and S0 + n_new on return (capacity is the caller's).  Each new scaffold enters in '+'
+    // orientation (it has never been flipped, OG:265) and leaves checkAllScores in the winning
+    // orientation - '+' when nothing scored above 0 (OG:341, 367-368) - at the winning gap (0 by default).
+    if (!c || !ids || !rev || !new_ids || !best_out || S0 < 1 || n_new < 1) return fail(HICMI_EINVAL, "bad arguments");
+    int64_t S = S0;
+    double best = 0.0;
+    for (int64_t t = 0; t < n_new; t++) {
+        int64_t gap = -1; int32_t r = 0;
+        int rc = hicmi_p2_decide_insertion(c, ids, rev, S, new_ids[t], 0, &gap, &r, &best);
+        if (rc) return rc;
+        if (gap < 0) { gap = 0; r = 0; best = 0.0; }
+        for (int64_t j = S; j > gap; j--) { ids[j] = ids[j - 1]; rev[j] = rev[j - 1]; }
+        ids[gap] = new_ids[t]; rev[gap] = (uint8_t)(r ? 1 : 0);
+        S++;
+    }
+    *best_out = best;
+    return HICMI_OK;
+}
+
+int hicmi_p2_scan_pass(hicmi_ctx* c, int32_t* ids, uint8_t* rev, int64_t S, int64_t k, double total, double* best_io,
+                       double* cur_fast_io, int32_t* improved_out)
+{
+    // one round of scanOrdering (OG:513-541): windows first = 0 .. S-k, each applied before the next
+    if (!c || !ids || !rev || !best_io || !cur_fast_io || !improved_out || S < 1 || k < 1 || k > S)
+        return fail(HICMI_EINVAL, "bad arguments");
+    if (k != c->tab_k || c->h_orders.empty()) return fail(HICMI_EINVAL, "hicmi_p2_window_tables has not been called for k = %lld", (long long)k);
+    *improved_out = 0;
+    const int64_t n_ori = c->n_orients;
+    int rc = hicmi_p2_set_arrangement(c, ids, rev, S);
+    if (rc) return rc;
+    for (int64_t first = 0; first + k <= S; first++) {
+        int64_t pick = -1; double best = *best_io, pf = *cur_fast_io;
+        rc = hicmi_p2_decide_window(c, first, k, total, *best_io, *cur_fast_io, &pick, &best, &pf);
+        if (rc) return rc;
+        *cur_fast_io = pf;
+        if (pick < 0) continue;
+        *best_io = best; *improved_out = 1;
+        const int8_t* ord = c->h_orders.data() + (pick / n_ori) * k;
+        const uint8_t* ori = c->h_orients.data() + (pick % n_ori) * k;
+        int32_t wid[8];
+        for (int64_t j = 0; j < k; j++) wid[j] = ids[first + ord[j]];
+        for (int64_t j = 0; j < k; j++) { ids[first + j] = wid[j]; rev[first + j] = ori[j] ? 1 : 0; }
+        rc = hicmi_p2_set_arrangement(c, ids, rev, S);
+        if (rc) return rc;
+    }
+    return HICMI_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 int hicmi_timing_reset(hicmi_ctx* c)
 {

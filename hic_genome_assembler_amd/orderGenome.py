@@ -60,11 +60,12 @@ class ChromosomeLayout:
     def __init__(self, matrix: GenomeMatrix, scaffolds, binList):
         self.ctx = matrix.ctx
         where = matrix.bin_index(binList)
-        self.sid, self.start, self.length = {}, [], []
+        self.sid, self.start, self.length, self.names = {}, [], [], []
         sel, pos = [], 0
         for s in scaffolds:
             bins = sorted(s.binList)
             self.sid[s.name] = len(self.start)
+            self.names.append(s.name)
             self.start.append(pos)
             self.length.append(len(bins))
             sel += [where[b] for b in bins]
@@ -495,6 +496,17 @@ def checkAllScores(adjMat: SubMatrix, orderDict, orderedScaffs, scaffToCheck):
 
 def orderRemainderScaffolds(orderedScaffolds, scaffoldList, orderDict, matrix: GenomeMatrix, binList):
     """OG:475-493 (a do-while: with nothing left to add, the last ordered scaffold is re-inserted)."""
+    layout = matrix.chrom
+    if (layout is not None and _fused(matrix.ctx) and len(scaffoldList) > 0 and len(orderedScaffolds) > 0
+            and layout.covers(orderedScaffolds) and layout.covers(scaffoldList)
+            and all(s.orientation == "+" for s in scaffoldList)):
+        ids, rev = layout.describe(orderedScaffolds)
+        new_ids = [layout.sid[s.name] for s in scaffoldList]
+        by_name = {s.name: s for s in orderedScaffolds + scaffoldList}
+        ids, rev, bestCost = matrix.ctx.p2_insert_all(ids, rev, new_ids)
+        del scaffoldList[:]
+        orderedScaffolds, _nodes = reorderScaffList([layout.names[i] for i in ids], ["-" if r else "+" for r in rev], by_name)
+        return orderedScaffolds, bestCost
     while True:
         orderedScaffolds, scaffoldList = pullScaffolds(orderedScaffolds, scaffoldList, 1)
         adjMat, orderDict = giveNewAdjMat(matrix, orderedScaffolds, binList)
@@ -517,6 +529,21 @@ def scanOrdering(orderedScaffolds, scaffoldDict, orderDict, matrix: GenomeMatrix
     w = scanScaffolds
     orders, orients = _enumeration(w)
     cur_fast = None                                     # fast score of the current arrangement
+    if _fused(adjMat.ctx):
+        layout = adjMat.layout
+        layout.tables(w)
+        ids, rev = layout.describe(orderedScaffolds)
+        while True:
+            print("Working on round " + str(roundNumber + 1) + " of final step...")
+            ids, rev, bestCost, cur_fast, improved = adjMat.ctx.p2_scan_pass(ids, rev, w, total, bestCost, cur_fast)
+            roundNumber += 1
+            if not improved:
+                break
+        orderedScaffolds, _nodes = reorderScaffList([layout.names[i] for i in ids], ["-" if r else "+" for r in rev],
+                                                    scaffoldDict)
+        print("Sliding window conversion after " + str(roundNumber) + " rounds")
+        print("Best cost at the end of the final step = " + str(bestCost))
+        return orderedScaffolds, bestCost
     while True:
         improved = False
         print("Working on round " + str(roundNumber + 1) + " of final step...")

@@ -182,6 +182,19 @@ int hicmi_p2_decide_window(hicmi_ctx *ctx, int64_t first, int64_t k, double tota
 int hicmi_p2_decide_insertion(hicmi_ctx *ctx, const int32_t *ids, const uint8_t *rev, int64_t S, int32_t new_id,
                               int32_t new_rev_now, int64_t *gap_out, int32_t *rev_out, double *best_out);
 
+/* Whole loops, so that one chromosome costs a handful of host calls (chromosomes are independent and
+ * are driven concurrently from host threads, one context each).
+ * hicmi_p2_insert_all = orderRemainderScaffolds (OG:475-493): ids/rev hold the S0 ordered scaffolds on
+ * entry and S0 + n_new on return (caller provides the capacity); new_ids are the remaining scaffolds
+ * in pull order, each entering in '+' orientation.  best_out = bestCost of the last insertion.
+ * hicmi_p2_scan_pass = one round of scanOrdering (OG:513-541) over windows of k scaffolds, every
+ * winner applied before the next window; ids/rev updated in place, *best_io / *cur_fast_io carried,
+ * *improved_out = 1 if any window improved (the reference's `stop`). */
+int hicmi_p2_insert_all(hicmi_ctx *ctx, int32_t *ids, uint8_t *rev, int64_t S0, const int32_t *new_ids, int64_t n_new,
+                        double *best_out);
+int hicmi_p2_scan_pass(hicmi_ctx *ctx, int32_t *ids, uint8_t *rev, int64_t S, int64_t k, double total, double *best_io,
+                       double *cur_fast_io, int32_t *improved_out);
+
 /* ---- timing ----------------------------------------------------------------------------------
  * Accumulated device time (HIP events on the context stream) per kernel family since the last
  * reset, for bench.py's roofline object.  names_out: caller buffer receiving ';'-separated names;
