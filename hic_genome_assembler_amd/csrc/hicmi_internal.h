@@ -13,8 +13,8 @@ void launch_compact(const double* src, int64_t ld_src, const int32_t* keep, int 
 void launch_build_w(const double* C, int64_t ldc, const double* np_sum, int n, double* W, int64_t ldw, hipStream_t s);
 // k_nnchain.hip
 size_t nnchain_workspace_bytes(int n);
-void launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double* zraw, void* workspace, bool profile,
-                    int dcap, bool compact, hipStream_t s);
+int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double* zraw, void* workspace, bool profile,
+                   int dcap, bool compact, hipStream_t s);   // returns the number of k_nn_epoch launches
 const int* nnchain_state_ptr(void* workspace);                    // [0] merges done ... [5] guard tripped
 const unsigned long long* nnchain_prof_ptr(void* workspace);      // 5 phase totals (100 MHz ticks)
 void launch_cut_count(const uint16_t* rank, int64_t ldr, int row0, int nrows, int lo, int mode, int cparam,

@@ -377,9 +377,11 @@ __global__ __launch_bounds__(256) void k_nn_translate(double* __restrict__ zraw,
 }
 
 // W and W2: two n x ldw buffers (W holds the distances on entry; both are scratch afterwards).
-void launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double* zraw, void* workspace, bool profile,
-                    int dcap, bool compact, hipStream_t s)
+// Returns the number of k_nn_epoch launches.
+int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double* zraw, void* workspace, bool profile,
+                   int dcap, bool compact, hipStream_t s)
 {
+    int epochs = 0;
     NNWorkspace w = carve(workspace, n);
     if (dcap < 1) dcap = 1;
     if (dcap > NN_DMAX) dcap = NN_DMAX;
@@ -398,6 +400,7 @@ void launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, doubl
         const size_t lds = align16((size_t)nw4 * 8 + (size_t)n_cur * 2);
         if (profile) hipLaunchKernelGGL(k_nn_epoch<true>, dim3(1), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
         else hipLaunchKernelGGL(k_nn_epoch<false>, dim3(1), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+        epochs++;
         const int did = total_steps - done < dcap ? total_steps - done : dcap;
         done += did;
         if (done >= total_steps) break;
@@ -415,6 +418,7 @@ void launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, doubl
     }
     hipLaunchKernelGGL(k_nn_translate, dim3((total_steps - interval_start + 255) / 256), dim3(256), 0, s, zraw, interval_start,
                        total_steps, w);
+    return epochs;
 }
 
 // status word and phase profile live at the start of the workspace
