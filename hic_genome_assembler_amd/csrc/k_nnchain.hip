@@ -105,8 +105,8 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_nn[];
     const int nwords = (n + 31) >> 5, nw4 = (nwords + 3) & ~3;
     uint32_t* alive = reinterpret_cast<uint32_t*>(smem_nn);
-    uint32_t* dmask = alive + nw4;
-    uint16_t* lsize = reinterpret_cast<uint16_t*>(dmask + nw4);
+    uint32_t* smask = alive + nw4;                          // alive AND not dirty: what the streaming passes visit
+    uint16_t* lsize = reinterpret_cast<uint16_t*>(smask + nw4);
     __shared__ int dslot[NN_DMAX], dtime[NN_DMAX];
     __shared__ double s_v[16];
     __shared__ int s_i[16];
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
         if (tid == 0) w.state[6] = 0;
         return;
     }
-    for (int i = tid; i < nwords; i += NN_THREADS) { alive[i] = w.alive[i]; dmask[i] = 0u; }
+    for (int i = tid; i < nwords; i += NN_THREADS) { alive[i] = w.alive[i]; smask[i] = w.alive[i]; }
     for (int i = tid; i < n; i += NN_THREADS) { lsize[i] = w.size[i]; w.gtime[i] = -1; }
     // lane-0 private chain state
     int len = w.state[1], top = w.state[2], second = w.state[3], first_ptr = w.state[4], ring_lo = len;
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
     if (tid == 0) { s_stop = 0; s_done = 0; }
     __syncthreads();
     int D = 0;                                              // dirty entries (uniform across lanes)
+    uint32_t xbit = 0u;                                     // lane 0: the scan row's own bit in smask
 
     for (; step < total_steps && D < dcap; step++) {
         if (PROFILE && tid == 0) t0 = wall_clock64();
@@ -139,7 +140,11 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
         double cur = 0.0;
         int ybest = -1;
         while (true) {
-            if (tid == 0) { s_x = top; s_prev = (len > 1) ? second : -1; s_tx = -1; }
+            if (tid == 0) {
+                s_x = top; s_prev = (len > 1) ? second : -1; s_tx = -1;
+                xbit = smask[top >> 5] & (1u << (top & 31));         // the row's own column is skipped by masking it
+                smask[top >> 5] &= ~xbit;
+            }
             __syncthreads();
             const int x = s_x, prev = s_prev;
             if (tid < D && dslot[tid] == x) s_tx = dtime[tid];       // is the row itself dirty, and since when
@@ -147,27 +152,27 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
             if (PROFILE && tid == 0) { t1 = wall_clock64(); t_book += t1 - t0; t0 = t1; }
             const int tx = s_tx;
             const double* __restrict__ rowx = W + (int64_t)x * ld;
-            ArgMin best = {__builtin_inf(), 0x7fffffff};
+            // d(x, previous chain element) when that element is clean (a dirty one is handled below)
+            if (tid == 64 && prev >= 0 && ((smask[prev >> 5] >> (prev & 31)) & 1u)) s_dprev = rowx[prev];
             // dirty partners: the value comes from whichever row was rewritten last
+            ArgMin cand = {__builtin_inf(), 0x7fffffff};
             if (tid < D) {
                 const int d = dslot[tid];
                 if (d >= 0 && d != x && ((alive[d >> 5] >> (d & 31)) & 1u)) {
                     const double v = dtime[tid] > tx ? W[(int64_t)d * ld + x] : rowx[d];
-                    best.v = v; best.i = d;
+                    cand.v = v; cand.i = d;
                     if (d == prev) s_dprev = v;
                 }
             }
+            ArgMin best = {__builtin_inf(), 0x7fffffff};
 #pragma unroll 4
-            for (int j = tid * 2; j < n; j += 2 * NN_THREADS) {
+            for (int j = tid * 2; j < n; j += 2 * NN_THREADS) {     // ascending j per lane: strict '<' keeps the lowest index
                 double2 v = *reinterpret_cast<const double2*>(rowx + j);
-                uint32_t bits = (alive[j >> 5] & ~dmask[j >> 5]) >> (j & 31);     // j even: both bits in one word
-                if ((bits & 1u) && j != x && (v.x < best.v || (v.x == best.v && j < best.i))) { best.v = v.x; best.i = j; }
-                if ((bits & 2u) && j + 1 != x && j + 1 < n && (v.y < best.v || (v.y == best.v && j + 1 < best.i))) {
-                    best.v = v.y; best.i = j + 1;
-                }
-                if ((prev | 1) == (j | 1) && prev >= 0 && !((dmask[prev >> 5] >> (prev & 31)) & 1u))
-                    s_dprev = (prev & 1) ? v.y : v.x;                              // d(x, previous chain element)
+                uint32_t bits = smask[j >> 5] >> (j & 31);          // j even: both bits in one word; bits past n are 0
+                if ((bits & 1u) && v.x < best.v) { best.v = v.x; best.i = j; }
+                if ((bits & 2u) && v.y < best.v) { best.v = v.y; best.i = j + 1; }
             }
+            if (cand.v < best.v || (cand.v == best.v && cand.i < best.i)) best = cand;
             best = argmin_wave(best);
             if (lane == 0) { s_v[wave] = best.v; s_i[wave] = best.i; }
             __syncthreads();
@@ -189,6 +194,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
                         second = top; top = y; len++;
                     }
                     cur = c; ybest = y;
+                    smask[x >> 5] |= xbit;                          // un-mask the row's own column
                     s_done = done;
                 }
             }
@@ -209,6 +215,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
             lsize[xx] = 0;
             lsize[yy] = (uint16_t)(nx + ny);
             alive[xx >> 5] &= ~(1u << (xx & 31));
+            smask[xx >> 5] &= ~(1u << (xx & 31));
             s_mx = xx; s_my = yy; s_nx = nx; s_ny = ny; s_tx = -1; s_ty = -1; s_ey = -1;
             top = len >= 1 ? (len - 1 >= ring_lo ? ring[(len - 1) & 255] : chain[len - 1]) : -1;
             second = len >= 2 ? (len - 2 >= ring_lo ? ring[(len - 2) & 255] : chain[len - 2]) : -1;
@@ -242,9 +249,9 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
             for (int j = tid * 2; j < n; j += 2 * NN_THREADS) {
                 double2 a = *reinterpret_cast<const double2*>(rx + j);
                 double2 b = *reinterpret_cast<const double2*>(ry + j);
-                uint32_t bits = (alive[j >> 5] & ~dmask[j >> 5]) >> (j & 31);
+                uint32_t bits = smask[j >> 5] >> (j & 31);
                 if ((bits & 1u) && j != my) b.x = (fx * a.x + fy * b.x) / fs;
-                if ((bits & 2u) && j + 1 != my && j + 1 < n) b.y = (fx * a.y + fy * b.y) / fs;
+                if ((bits & 2u) && j + 1 != my) b.y = (fx * a.y + fy * b.y) / fs;
                 *reinterpret_cast<double2*>(ry + j) = b;
             }
             __syncthreads();
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
             if (tid == 0) {                                 // cluster y is dirty from now on
                 if (s_ey >= 0) dslot[s_ey] = -1;            // its older entry is superseded
                 dslot[D] = my; dtime[D] = step;
-                dmask[my >> 5] |= 1u << (my & 31);
+                smask[my >> 5] &= ~(1u << (my & 31));
             }
             D++;
         }
