@@ -40,6 +40,7 @@ SIGNATURES = {
     "hicmi_cut_scan": (ctypes.c_int, [_vp, c_i64, c_i64, c_dbl, _vp, _vp]),
     "hicmi_filter_scan": (ctypes.c_int, [_vp, c_i64, c_i64, c_i64, c_i64, c_dbl, _vp, _vp]),
     "hicmi_hypergeom_sf": (c_dbl, [c_i64, c_i64, c_i64, c_i64]),
+    "hicmi_selftest_division": (ctypes.c_int, [_vp, ctypes.c_uint64, c_i64, ctypes.POINTER(ctypes.c_uint64)]),
     "hicmi_label_linkage": (ctypes.c_int, [_vp, c_i64, _vp]),
     "hicmi_leaf_order": (ctypes.c_int, [_vp, c_i64, _vp]),
     "hicmi_get_raw_merges": (ctypes.c_int, [_vp, _vp]),
@@ -191,6 +192,11 @@ class Context:
         leaves = np.empty(self.n, np.int32)
         _check(self._lib.hicmi_upgma(self._h, _ptr(z), _ptr(leaves)))
         return leaves, z
+
+    def selftest_division(self, samples=1 << 28, seed=12345):
+        bad = ctypes.c_uint64()
+        _check(self._lib.hicmi_selftest_division(self._h, seed, samples, ctypes.byref(bad)))
+        return bad.value
 
     def raw_merges(self):
         z = np.empty((max(self.n - 1, 0), 4), np.float64)

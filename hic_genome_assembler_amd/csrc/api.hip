@@ -316,6 +316,24 @@ int hicmi_compact(hicmi_ctx* c, const int32_t* keep, int64_t n_keep)
     return compute_sums(c);
 }
 
+int hicmi_selftest_division(hicmi_ctx* c, uint64_t seed, int64_t samples, uint64_t* mismatches_out)
+{
+    if (!c || !mismatches_out || samples < 1) return fail(HICMI_EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    unsigned long long* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d, 0, sizeof(unsigned long long), c->stream));
+    const int blocks = 2048, iters = (int)std::max<int64_t>(1, samples / (blocks * 256));
+    launch_selftest_division(seed, blocks, iters, d, c->stream);
+    HIPCHK(hipGetLastError());
+    unsigned long long bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, d, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(d);
+    *mismatches_out = bad;
+    return HICMI_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 int hicmi_label_linkage(const double* zraw, int64_t n, double* Z)
 {

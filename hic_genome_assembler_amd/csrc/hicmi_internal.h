@@ -15,6 +15,7 @@ void launch_build_w(const double* C, int64_t ldc, const double* np_sum, int n, d
 size_t nnchain_workspace_bytes(int n);
 int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double* zraw, void* workspace, bool profile,
                    int dcap, bool compact, hipStream_t s);   // returns the number of k_nn_epoch launches
+void launch_selftest_division(unsigned long long seed, int blocks, int iters, unsigned long long* d_mismatches, hipStream_t s);
 const int* nnchain_state_ptr(void* workspace);                    // [0] merges done ... [5] guard tripped
 const unsigned long long* nnchain_prof_ptr(void* workspace);      // 5 phase totals (100 MHz ticks)
 void launch_cut_count(const uint16_t* rank, int64_t ldr, int row0, int nrows, int lo, int mode, int cparam,

@@ -30,6 +30,19 @@ static constexpr int NN_DMAX = 1024;                     // at most one dirty en
 
 struct ArgMin { double v; int i; };
 
+// num / fs, correctly rounded, for fs an integer-valued double below 2^17 and rcp = RN(1 / fs):
+// q0 = RN(num*rcp) is within 2 ulp of the quotient, r = num - fs*q0 is exact in an FMA, and
+// q0 + r*rcp equals num/fs to within 2^-105 relative - far closer than a quotient with a 17-bit
+// divisor can come to a rounding boundary (>= 2^-71 relative) - so the final rounding is the correct
+// one.  Three instructions instead of the ~30 of a general fp64 division; hicmi_selftest_division
+// compares it with '/' on random operands.
+__device__ __forceinline__ double div_by_small_int(double num, double fs, double rcp)
+{
+    double q = num * rcp;
+    double r = fma(-fs, q, num);
+    return fma(r, rcp, q);
+}
+
 __device__ __forceinline__ ArgMin argmin_wave(ArgMin a)
 {
 #pragma unroll
@@ -231,6 +244,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
         {
             const int tmx = s_tx, tmy = s_ty;
             const double fx = (double)s_nx, fy = (double)s_ny, fs = (double)(s_nx + s_ny);
+            const double rcp = 1.0 / fs;
             const double* __restrict__ rx = W + (int64_t)mx * ld;
             double* __restrict__ ry = W + (int64_t)my * ld;
             // dirty partners first (their loads overlap the streaming pass); results are stored after
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
                 if (d >= 0 && d != my && ((alive[d >> 5] >> (d & 31)) & 1u)) {
                     const double dxi = dtime[tid] > tmx ? W[(int64_t)d * ld + mx] : rx[d];
                     const double dyi = dtime[tid] > tmy ? W[(int64_t)d * ld + my] : ry[d];
-                    dv = (fx * dxi + fy * dyi) / fs;
+                    dv = div_by_small_int(fx * dxi + fy * dyi, fs, rcp);
                     dd = d;
                 }
             }
@@ -250,8 +264,8 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
                 double2 a = *reinterpret_cast<const double2*>(rx + j);
                 double2 b = *reinterpret_cast<const double2*>(ry + j);
                 uint32_t bits = smask[j >> 5] >> (j & 31);
-                if ((bits & 1u) && j != my) b.x = (fx * a.x + fy * b.x) / fs;
-                if ((bits & 2u) && j + 1 != my) b.y = (fx * a.y + fy * b.y) / fs;
+                if ((bits & 1u) && j != my) b.x = div_by_small_int(fx * a.x + fy * b.x, fs, rcp);
+                if ((bits & 2u) && j + 1 != my) b.y = div_by_small_int(fx * a.y + fy * b.y, fs, rcp);
                 *reinterpret_cast<double2*>(ry + j) = b;
             }
             __syncthreads();
@@ -426,6 +440,31 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     hipLaunchKernelGGL(k_nn_translate, dim3((total_steps - interval_start + 255) / 256), dim3(256), 0, s, zraw, interval_start,
                        total_steps, w);
     return epochs;
+}
+
+// ---- self test of div_by_small_int against the hardware-correct '/' ------------------------------------
+__global__ __launch_bounds__(256) void k_selftest_division(unsigned long long seed, int iters, unsigned long long* mismatches)
+{
+    unsigned long long st = seed ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(blockIdx.x * 256 + threadIdx.x + 1));
+    unsigned long long bad = 0;
+    for (int it = 0; it < iters; it++) {
+        st ^= st << 13; st ^= st >> 7; st ^= st << 17;                       // xorshift64
+        const unsigned long long r1 = st;
+        st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+        const unsigned long long r2 = st;
+        // numerator: random mantissa, exponent spread over 2^-8 .. 2^24; divisor: integer in [2, 131071]
+        const int e = (int)(r2 % 33u) - 8;
+        const double a = ldexp(1.0 + (double)(r1 >> 12) * (1.0 / 4503599627370496.0), e);
+        const double fs = (double)(2 + (int)((r2 >> 8) % 131070u));
+        const double rcp = 1.0 / fs;
+        if (div_by_small_int(a, fs, rcp) != a / fs) bad++;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+void launch_selftest_division(unsigned long long seed, int blocks, int iters, unsigned long long* d_mismatches, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_division, dim3(blocks), dim3(256), 0, s, seed, iters, d_mismatches);
 }
 
 // status word and phase profile live at the start of the workspace

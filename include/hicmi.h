@@ -108,6 +108,10 @@ double hicmi_hypergeom_sf(int64_t x, int64_t M, int64_t n, int64_t N);
  * relabel, and the count-sorted leaf walk.  Exposed for tests. */
 int hicmi_label_linkage(const double *Zraw, int64_t n, double *Z_out);
 int hicmi_leaf_order(const double *Z, int64_t n, int32_t *leaves_out);
+/* Device self test: the Lance-Williams update divides by (nx+ny) with a 3-instruction exact sequence
+ * (k_nnchain.hip: div_by_small_int); this compares it with the '/' operator on `samples` random
+ * (numerator, integer divisor < 2^17) pairs and returns the number of mismatches (must be 0). */
+int hicmi_selftest_division(hicmi_ctx *ctx, uint64_t seed, int64_t samples, uint64_t *mismatches_out);
 /* Raw merges (x, y, height, size) in nn-chain merge order from the last hicmi_upgma. */
 int hicmi_get_raw_merges(hicmi_ctx *ctx, double *Zraw_out);
 

@@ -99,6 +99,13 @@ def test_upgma_deferred_columns_any_flush_period(hic, orc, monkeypatch, n, seed,
     assert np.array_equal(leaves, leaves_o)
 
 
+def test_exact_division_by_cluster_size_selftest(hic):
+    """k_nnchain's 3-instruction division by (nx+ny) against the '/' operator: 2^29 random operands."""
+    with hic.Context(0) as ctx:
+        assert ctx.selftest_division(samples=1 << 29, seed=2026) == 0
+        assert ctx.selftest_division(samples=1 << 26, seed=7) == 0
+
+
 def test_upgma_heavy_ties_bit_exact(hic, orc):
     rng = np.random.default_rng(11)
     c = rng.integers(1, 4, size=(200, 200)).astype(np.float64)
