@@ -31,6 +31,7 @@ SIGNATURES = {
     "hicmi_set_contacts_host": (ctypes.c_int, [_vp, _vp, c_i64]),
     "hicmi_set_contacts_device": (ctypes.c_int, [_vp, _vp, c_i64, c_i64]),
     "hicmi_contacts_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "hicmi_load_hicpro_matrix": (ctypes.c_int, [ctypes.c_char_p, _vp, c_i64, _vp, ctypes.c_int, ctypes.POINTER(c_i64)]),
     "hicmi_row_sums": (ctypes.c_int, [_vp, _vp, _vp]),
     "hicmi_compact": (ctypes.c_int, [_vp, _vp, c_i64]),
     "hicmi_upgma": (ctypes.c_int, [_vp, _vp, _vp]),
@@ -106,6 +107,16 @@ def _check(rc):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(_vp)
+
+
+def load_hicpro_matrix(path, bin_ids, threads: int = 0):
+    """Dense fp64 matrix from a HiC-Pro triplet file, parsed by libhicmi's multi-threaded host loader."""
+    ids = np.ascontiguousarray(bin_ids, dtype=np.int64)
+    n = len(ids)
+    out = np.empty((n, n), dtype=np.float64)
+    edges = c_i64()
+    _check(load().hicmi_load_hicpro_matrix(os.fsencode(path), _ptr(ids), n, _ptr(out), int(threads), ctypes.byref(edges)))
+    return out, edges.value
 
 
 def hypergeom_sf(x, M, n, N) -> float:

@@ -32,6 +32,8 @@ static int fail(int code, const char* fmt, ...)
     return code;
 }
 
+namespace hicmi { int set_error(int code, const char* msg) { return fail(code, "%s", msg); } }
+
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \
         hipError_t _e = (expr);                                                                   \

@@ -49,10 +49,20 @@ def initiateLoci(bedFile, biasFile, binID_dict=False):
     return bins
 
 
-def read_contact_matrix(matrixFile, binList, chunk_lines: int = 4_000_000) -> np.ndarray:
+def read_contact_matrix(matrixFile, binList, chunk_lines: int = 4_000_000, engine: str = "native") -> np.ndarray:
     """S2C:70-98: ``id1<TAB>id2<TAB>value`` triplets into a dense symmetric fp64 array in ``binList``
     order.  Triplets naming an unknown bin are skipped; each one sets [i][j] and [j][i]; when a
-    cell is named twice the later line wins, exactly as sequential assignment would."""
+    cell is named twice the later line wins, exactly as sequential assignment would.
+
+    ``engine="native"`` (default) is libhicmi's multi-threaded mmap + from_chars parser
+    (csrc/loader.hip); ``engine="pandas"`` is an independent second implementation kept for
+    cross-checking."""
+    if engine == "native":
+        from . import _lib
+        ids = np.fromiter((b.ID for b in binList), dtype=np.int64, count=len(binList))
+        mat, edges = _lib.load_hicpro_matrix(matrixFile, ids)
+        print("Edges added to adjacency matrix" + "\t" + str(edges))
+        return mat
     import pandas as pd
 
     n = len(binList)

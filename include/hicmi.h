@@ -60,6 +60,15 @@ int hicmi_set_contacts_device(hicmi_ctx *ctx, const double *d_contacts, int64_t 
  * independent - OG:608-612) can adopt it with hicmi_set_contacts_device instead of copying it. */
 int hicmi_contacts_device(hicmi_ctx *ctx, void **d_contacts_out, int64_t *n_out, int64_t *ld_out);
 
+/* Host-side loader (no GPU involved): buildAdjacencyMatrix's triplet parse (S2C:70-98, OG:65-93).
+ * `path`: HiC-Pro matrix file, lines "id1<TAB>id2<TAB>value"; bin_ids[0..n): the bin ID of every
+ * row; out: n*n doubles (zero-filled here).  Triplets naming an unknown ID are skipped, each one sets
+ * [i][j] and [j][i], a cell named twice keeps the later line's value, values are converted with
+ * correct rounding (as Python's float()).  threads <= 0: all hardware threads.  A malformed line is
+ * an error (the reference raises there).  edges_out (may be NULL): triplets used. */
+int hicmi_load_hicpro_matrix(const char *path, const int64_t *bin_ids, int64_t n, double *out, int threads,
+                             int64_t *edges_out);
+
 /* Row sums, both flavours the reference uses:
  *   np_sum[i]  = row.sum() as NumPy reduces it (pairwise, 8192-element chunks)   S2C:112, S2C:147
  *   seq_sum[i] = builtin sum() left to right                                     S2C:134

@@ -117,14 +117,50 @@ def test_loaders_match_oracle(tmp_path):
     assert [(b.ID, b.chrom, b.start, b.stop, b.bias) for b in bins] == \
         [(b.ID, b.chrom, b.start, b.stop, b.bias) for b in bins_o]
     assert len(bins) == 298                                      # two "nan" bias lines dropped (S2C:57)
-    m = hostio.read_contact_matrix(paths["hicProMatrixFile"], bins)
-    assert np.array_equal(m, orc.build_adjacency(paths["hicProMatrixFile"], bins_o))
+    ref = orc.build_adjacency(paths["hicProMatrixFile"], bins_o)
+    for engine in ("native", "pandas"):
+        m = hostio.read_contact_matrix(paths["hicProMatrixFile"], bins, engine=engine)
+        assert np.array_equal(m, ref), engine
     # duplicates: the later line wins, unknown IDs are skipped (S2C:84-89)
     dup = tmp_path / "dup.matrix"
     dup.write_text("1\t2\t5.0\n2\t1\t7.5\n1\t999999\t3.0\n3\t3\t1.25\n1\t2\t9.0\n2\t3\t0.1\n")
     some = bins[:3]
-    m2 = hostio.read_contact_matrix(str(dup), some)
-    assert np.array_equal(m2, orc.build_adjacency(str(dup), some))
+    for engine in ("native", "pandas"):
+        m2 = hostio.read_contact_matrix(str(dup), some, engine=engine)
+        assert np.array_equal(m2, orc.build_adjacency(str(dup), some)), engine
+    # what Python's split/int/float accept: CRLF, exponents, a fourth column, blanks around the value, no final newline
+    odd = tmp_path / "odd.matrix"
+    odd.write_text("1\t2\t5.0\r\n2\t3\t1e-3\n3\t1\t.5\textra\n2\t2\t 4.25 \n1\t1\t+7\n3\t3\t1E2")
+    assert np.array_equal(hostio.read_contact_matrix(str(odd), some), orc.build_adjacency(str(odd), some))
+    # many duplicates spread over the file: every thread boundary must still honour "the later line wins"
+    rng = np.random.default_rng(0)
+    big = tmp_path / "big.matrix"
+    ids = [b.ID for b in bins[:40]]
+    with open(big, "w") as fh:
+        for _ in range(60000):
+            a, b = rng.choice(ids, 2)
+            fh.write("%d\t%d\t%r\n" % (a, b, float(rng.random())))
+    forty = bins[:40]
+    assert np.array_equal(hostio.read_contact_matrix(str(big), forty), orc.build_adjacency(str(big), forty))
+    # number formats: HiC-Pro's 6 decimals (exact fast path), short/long significands, exponents, tiny and huge values
+    fmt = tmp_path / "formats.matrix"
+    with open(fmt, "w") as fh:
+        k = 0
+        for a in ids:
+            for b in ids:
+                if b < a:
+                    continue
+                x = float(rng.random() * 10 ** int(rng.integers(-12, 12)))
+                text = ["%.6f" % x, "%.3e" % x, "%r" % x, "%.15g" % x, "%.17g" % x, "%d" % int(x), "%.20f" % x,
+                        "%.1f" % x, "%e" % (x * 1e-300), "%e" % (x * 1e290)][k % 10]
+                fh.write("%d\t%d\t%s\n" % (a, b, text))
+                k += 1
+    assert np.array_equal(hostio.read_contact_matrix(str(fmt), forty), orc.build_adjacency(str(fmt), forty))
+    bad = tmp_path / "bad.matrix"
+    bad.write_text("1\t2\t5.0\n\n2\t3\t1.0\n")
+    from hic_genome_assembler_amd import _lib
+    with pytest.raises(_lib.HicmiError):
+        hostio.read_contact_matrix(str(bad), some)
     subset = {b.ID: '' for b in bins[10:20]}
     sub = hostio.initiateLoci(paths["hicProBedFile"], paths["hicProBiasFile"], binID_dict=subset)
     assert [b.ID for b in sub] == [b.ID for b in bins[10:20]]
