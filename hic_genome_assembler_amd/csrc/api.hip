@@ -94,6 +94,7 @@ struct hicmi_ctx {
     std::unordered_map<std::string, double> exact_cache;
     double* d_G = nullptr; int64_t g_cap = 0;
     double* d_delta = nullptr; int64_t delta_cap = 0;
+    WindowBatchEntry* d_wb = nullptr; int64_t wb_cap = 0;
 
     // timing
     bool timing = false;
@@ -228,7 +229,7 @@ int hicmi_destroy(hicmi_ctx* c)
     free_dev(c->d_partial); free_dev(c->d_T);
     free_dev(c->d_scaf_start); free_dev(c->d_scaf_len); free_dev(c->d_arr_packed);
     free_dev(c->d_pos2sel); free_dev(c->d_orders); free_dev(c->d_orients);
-    free_dev(c->d_G); free_dev(c->d_delta);
+    free_dev(c->d_G); free_dev(c->d_delta); free_dev(c->d_wb);
     for (auto& r : c->regions) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
@@ -868,45 +869,63 @@ int hicmi_p2_window_tables(hicmi_ctx* c, int64_t k, const int8_t* orders, int64_
     return HICMI_OK;
 }
 
-int hicmi_p2_score_window(hicmi_ctx* c, int64_t first, int64_t k, double* delta_out)
+namespace {
+// deltas of `count` consecutive windows (first0, first0+1, ...) of k scaffolds against the CURRENT
+// arrangement, one launch pair; delta_out: count x n_cand
+int window_batch(hicmi_ctx* c, int64_t first0, int64_t count, int64_t k, double* delta_out)
 {
-    if (!c || !delta_out) return fail(HICMI_EINVAL, "bad arguments");
     const int64_t S = (int64_t)c->h_arr_id.size();
     if (c->n_arr < 1 || S < 1) return fail(HICMI_EINVAL, "hicmi_p2_set_arrangement has not run");
     if (k != c->tab_k) return fail(HICMI_EINVAL, "hicmi_p2_window_tables has not been called for k = %lld", (long long)k);
-    if (first < 0 || first + k > S) return fail(HICMI_EINVAL, "window out of range");
+    if (first0 < 0 || count < 1 || first0 + count - 1 + k > S) return fail(HICMI_EINVAL, "window out of range");
     HIPCHK(hipSetDevice(c->device));
-    const int p0 = c->h_arr_pos[(size_t)first], p1 = c->h_arr_pos[(size_t)(first + k)], m = p1 - p0;
     const int64_t n_cand = c->n_orders * c->n_orients;
-    int rc = ensure(c->d_G, c->g_cap, (int64_t)m * m);
-    if (rc) return rc;
-    rc = ensure(c->d_delta, c->delta_cap, n_cand);
-    if (rc) return rc;
-    WindowDesc wd;
-    memset(&wd, 0, sizeof(wd));
-    for (int64_t j = 0; j < k; j++) {
-        const int32_t sc = c->h_arr_id[(size_t)(first + j)];
-        wd.start[j] = c->h_scaf_start[(size_t)sc];
-        wd.len[j] = c->h_scaf_len[(size_t)sc];
-        wd.off[j] = c->h_arr_pos[(size_t)(first + j)] - p0;
-        wd.rev[j] = c->h_arr_rev[(size_t)(first + j)];
+    std::vector<WindowBatchEntry> wb((size_t)count);
+    int64_t g_total = 0; int max_m = 0; double g_bytes = 0.0, d_bytes = 0.0;
+    for (int64_t wdx = 0; wdx < count; wdx++) {
+        const int64_t first = first0 + wdx;
+        WindowBatchEntry& e = wb[(size_t)wdx];
+        memset(&e, 0, sizeof(e));
+        const int p0 = c->h_arr_pos[(size_t)first], p1 = c->h_arr_pos[(size_t)(first + k)];
+        e.p0 = p0; e.m = p1 - p0; e.g_off = g_total;
+        for (int64_t j = 0; j < k; j++) {
+            const int32_t sc = c->h_arr_id[(size_t)(first + j)];
+            e.w.start[j] = c->h_scaf_start[(size_t)sc];
+            e.w.len[j] = c->h_scaf_len[(size_t)sc];
+            e.w.off[j] = c->h_arr_pos[(size_t)(first + j)] - p0;
+            e.w.rev[j] = c->h_arr_rev[(size_t)(first + j)];
+        }
+        g_total += (int64_t)e.m * e.m;
+        max_m = std::max(max_m, e.m);
+        g_bytes += 8.0 * (double)e.m * (double)(c->n_arr - e.m);
+        d_bytes += 8.0 * (double)n_cand * (0.5 * (double)e.m * (double)(e.m - 1) + (double)e.m);
     }
+    int rc = ensure(c->d_G, c->g_cap, g_total);
+    if (rc) return rc;
+    rc = ensure(c->d_delta, c->delta_cap, n_cand * count);
+    if (rc) return rc;
+    rc = ensure(c->d_wb, c->wb_cap, count);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->d_wb, wb.data(), sizeof(WindowBatchEntry) * (size_t)count, hipMemcpyHostToDevice, c->stream));
     {
-        Timed t(c, F_P2_WINDOW_G, 8.0 * (double)m * (double)(c->n_arr - m));
-        launch_p2_window_G(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, p0, m, c->d_H, c->d_G, c->stream);
+        // the G and delta kernels are launched as a pair; their algorithmic bytes are booked separately
+        c->launches[F_P2_WINDOW_DELTA]++; c->bytes[F_P2_WINDOW_DELTA] += d_bytes;
+        Timed t(c, F_P2_WINDOW_G, g_bytes);
+        launch_p2_window_batch(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, (int)k, c->d_wb, (int)count, max_m, c->d_orders,
+                               c->d_orients, (int)c->n_orders, (int)c->n_orients, c->d_H, c->d_G, c->d_delta, c->stream);
     }
     HIPCHK(hipGetLastError());
-    {
-        Timed t(c, F_P2_WINDOW_DELTA, 8.0 * (double)n_cand * (0.5 * (double)m * (double)(m - 1) + (double)m));
-        launch_p2_window_delta(c->dM2, c->ld2, (int)c->n_arr, m, (int)k, wd, c->d_orders, c->d_orients, (int)c->n_orders,
-                               (int)c->n_orients, c->d_H, c->d_G, c->d_delta, c->stream);
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(delta_out, c->d_delta, sizeof(double) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(delta_out, c->d_delta, sizeof(double) * (size_t)(n_cand * count), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return HICMI_OK;
 }
+}  // namespace
 
+int hicmi_p2_score_window(hicmi_ctx* c, int64_t first, int64_t k, double* delta_out)
+{
+    if (!c || !delta_out) return fail(HICMI_EINVAL, "bad arguments");
+    return window_batch(c, first, 1, k, delta_out);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Whole decision steps in one call: fast scores of every candidate (device enumeration), short list
@@ -976,38 +995,34 @@ void short_list(const std::vector<double>& fast, double floor, std::vector<int64
 }
 }  // namespace
 
-int hicmi_p2_decide_window(hicmi_ctx* c, int64_t first, int64_t k, double total, double floor, double cur_fast,
-                           int64_t* pick_out, double* best_out, double* pick_fast_out)
+namespace {
+// the decision of one window from its deltas; cur_fast (fast score of the current arrangement) is
+// computed on first use when NaN
+int decide_from_delta(hicmi_ctx* c, int64_t first, int64_t k, double total, double floor, double& cur_fast,
+                      const double* delta, int64_t* pick_out, double* best_out, double* pick_fast_out)
 {
-    if (!c || !pick_out || !best_out || !pick_fast_out) return fail(HICMI_EINVAL, "NULL argument");
     const int64_t S = (int64_t)c->h_arr_id.size();
-    if (c->n_arr < 1 || S < 1) return fail(HICMI_EINVAL, "hicmi_p2_set_arrangement has not run");
-    if (k != c->tab_k || c->h_orders.empty()) return fail(HICMI_EINVAL, "hicmi_p2_window_tables has not been called for k = %lld", (long long)k);
-    if (first < 0 || first + k > S) return fail(HICMI_EINVAL, "window out of range");
     const int64_t n_ord = c->n_orders, n_ori = c->n_orients, n_cand = n_ord * n_ori;
     *pick_out = -1; *best_out = floor; *pick_fast_out = cur_fast;
-    use_total(c, total);
     // candidate index of the current configuration: identity order + the window's current signs
     int64_t c0 = -1;
-    for (int64_t j = 0; j < k; j++) if (c->h_orders[(size_t)j] != j) return fail(HICMI_EINVAL, "orders[0] must be the identity");
     for (int64_t r = 0; r < n_ori && c0 < 0; r++) {
         bool same = true;
         for (int64_t j = 0; j < k; j++) same = same && ((c->h_orients[(size_t)(r * k + j)] != 0) == (c->h_arr_rev[(size_t)(first + j)] != 0));
         if (same) c0 = r;
     }
     if (c0 < 0) return fail(HICMI_EINVAL, "current orientation not in the orientation table");
-    std::vector<double> delta((size_t)n_cand);
-    int rc = hicmi_p2_score_window(c, first, k, delta.data());
-    if (rc) return rc;
     std::vector<double> fast((size_t)n_cand);
+    int rc;
     if (k == S) for (int64_t i = 0; i < n_cand; i++) fast[(size_t)i] = delta[(size_t)i] / total;
     else {
         if (std::isnan(cur_fast)) { rc = hicmi_p2_arrangement_score(c, total, &cur_fast); if (rc) return rc; }
         for (int64_t i = 0; i < n_cand; i++) fast[(size_t)i] = cur_fast + (delta[(size_t)i] - delta[(size_t)c0]) / total;
     }
+    *pick_fast_out = cur_fast;
     std::vector<int64_t> near;
     short_list(fast, floor, near);
-    if (near.empty()) { *pick_fast_out = cur_fast; return HICMI_OK; }
+    if (near.empty()) return HICMI_OK;
     const int p0 = c->h_arr_pos[(size_t)first], p1 = c->h_arr_pos[(size_t)(first + k)];
     std::vector<std::vector<int32_t>> rows(near.size());
     for (size_t q = 0; q < near.size(); q++) {
@@ -1031,8 +1046,32 @@ int hicmi_p2_decide_window(hicmi_ctx* c, int64_t first, int64_t k, double total,
     double best = floor; int64_t pick = -1;
     for (size_t q = 0; q < near.size(); q++) if (lit[q] > best) { best = lit[q]; pick = near[q]; }
     *pick_out = pick; *best_out = best;
-    *pick_fast_out = pick >= 0 ? fast[(size_t)pick] : cur_fast;
+    if (pick >= 0) *pick_fast_out = fast[(size_t)pick];
     return HICMI_OK;
+}
+
+int check_window_call(hicmi_ctx* c, int64_t first, int64_t k)
+{
+    const int64_t S = (int64_t)c->h_arr_id.size();
+    if (c->n_arr < 1 || S < 1) return fail(HICMI_EINVAL, "hicmi_p2_set_arrangement has not run");
+    if (k != c->tab_k || c->h_orders.empty()) return fail(HICMI_EINVAL, "hicmi_p2_window_tables has not been called for k = %lld", (long long)k);
+    if (first < 0 || first + k > S) return fail(HICMI_EINVAL, "window out of range");
+    for (int64_t j = 0; j < k; j++) if (c->h_orders[(size_t)j] != j) return fail(HICMI_EINVAL, "orders[0] must be the identity");
+    return HICMI_OK;
+}
+}  // namespace
+
+int hicmi_p2_decide_window(hicmi_ctx* c, int64_t first, int64_t k, double total, double floor, double cur_fast,
+                           int64_t* pick_out, double* best_out, double* pick_fast_out)
+{
+    if (!c || !pick_out || !best_out || !pick_fast_out) return fail(HICMI_EINVAL, "NULL argument");
+    int rc = check_window_call(c, first, k);
+    if (rc) return rc;
+    use_total(c, total);
+    std::vector<double> delta((size_t)(c->n_orders * c->n_orients));
+    rc = window_batch(c, first, 1, k, delta.data());
+    if (rc) return rc;
+    return decide_from_delta(c, first, k, total, floor, cur_fast, delta.data(), pick_out, best_out, pick_fast_out);
 }
 
 int hicmi_p2_decide_insertion(hicmi_ctx* c, const int32_t* ids, const uint8_t* rev, int64_t S, int32_t new_id,
@@ -1122,28 +1161,50 @@ int hicmi_p2_insert_all(hicmi_ctx* c, int32_t* ids, uint8_t* rev, int64_t S0, co
 int hicmi_p2_scan_pass(hicmi_ctx* c, int32_t* ids, uint8_t* rev, int64_t S, int64_t k, double total, double* best_io,
                        double* cur_fast_io, int32_t* improved_out)
 {
-    // one round of scanOrdering (OG:513-541): windows first = 0 .. S-k, each applied before the next
+    // one round of scanOrdering (OG:513-541): windows first = 0 .. S-k, each applied before the next.
+    // Until a window improves, all of them see the same arrangement, so they are scored in batches of
+    // up to 32 windows per launch pair; after an improvement the remaining windows are scored again
+    // against the new arrangement.
     if (!c || !ids || !rev || !best_io || !cur_fast_io || !improved_out || S < 1 || k < 1 || k > S)
         return fail(HICMI_EINVAL, "bad arguments");
-    if (k != c->tab_k || c->h_orders.empty()) return fail(HICMI_EINVAL, "hicmi_p2_window_tables has not been called for k = %lld", (long long)k);
     *improved_out = 0;
-    const int64_t n_ori = c->n_orients;
+    const int64_t n_ori = c->n_orients, n_cand = c->n_orders * c->n_orients;
     int rc = hicmi_p2_set_arrangement(c, ids, rev, S);
     if (rc) return rc;
-    for (int64_t first = 0; first + k <= S; first++) {
-        int64_t pick = -1; double best = *best_io, pf = *cur_fast_io;
-        rc = hicmi_p2_decide_window(c, first, k, total, *best_io, *cur_fast_io, &pick, &best, &pf);
+    rc = check_window_call(c, 0, k);
+    if (rc) return rc;
+    use_total(c, total);
+    const int64_t last = S - k;
+    std::vector<double> delta;
+    int64_t first = 0;
+    int64_t batch = 8;                                   // grows while no window improves
+    while (first <= last) {
+        const int64_t count = std::min<int64_t>(batch, last - first + 1);
+        delta.resize((size_t)(count * n_cand));
+        rc = window_batch(c, first, count, k, delta.data());
         if (rc) return rc;
-        *cur_fast_io = pf;
-        if (pick < 0) continue;
-        *best_io = best; *improved_out = 1;
-        const int8_t* ord = c->h_orders.data() + (pick / n_ori) * k;
-        const uint8_t* ori = c->h_orients.data() + (pick % n_ori) * k;
-        int32_t wid[8];
-        for (int64_t j = 0; j < k; j++) wid[j] = ids[first + ord[j]];
-        for (int64_t j = 0; j < k; j++) { ids[first + j] = wid[j]; rev[first + j] = ori[j] ? 1 : 0; }
-        rc = hicmi_p2_set_arrangement(c, ids, rev, S);
-        if (rc) return rc;
+        bool applied = false;
+        for (int64_t wdx = 0; wdx < count && !applied; wdx++) {
+            int64_t pick = -1; double best = *best_io, pf = *cur_fast_io;
+            double cf = *cur_fast_io;
+            rc = decide_from_delta(c, first + wdx, k, total, *best_io, cf, delta.data() + wdx * n_cand, &pick, &best, &pf);
+            if (rc) return rc;
+            *cur_fast_io = pf;
+            if (pick < 0) continue;
+            *best_io = best; *improved_out = 1;
+            const int64_t f = first + wdx;
+            const int8_t* ord = c->h_orders.data() + (pick / n_ori) * k;
+            const uint8_t* ori = c->h_orients.data() + (pick % n_ori) * k;
+            int32_t wid[8];
+            for (int64_t j = 0; j < k; j++) wid[j] = ids[f + ord[j]];
+            for (int64_t j = 0; j < k; j++) { ids[f + j] = wid[j]; rev[f + j] = ori[j] ? 1 : 0; }
+            rc = hicmi_p2_set_arrangement(c, ids, rev, S);
+            if (rc) return rc;
+            first = f + 1;
+            applied = true;
+            batch = 8;
+        }
+        if (!applied) { first += count; batch = std::min<int64_t>(batch * 2, 32); }
     }
     return HICMI_OK;
 }

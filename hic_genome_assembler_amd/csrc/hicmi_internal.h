@@ -57,10 +57,13 @@ void launch_p2_base_partial(const double* M2, int64_t ld2, const int32_t* pos2se
                             int n_blocks, double* out, hipStream_t s);
 void launch_p2_insert_delta(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const int32_t* arr_pos,
                             int S, int new_start, int L, const double* H, int n_base_blocks, double* out, hipStream_t s);
-void launch_p2_window_G(const double* M2, int64_t ld2, const int32_t* pos2sel, int n, int p0, int m, const double* H,
-                        double* G, hipStream_t s);
-void launch_p2_window_delta(const double* M2, int64_t ld2, int n, int m, int k, const WindowDesc& w, const int8_t* orders,
-                            const uint8_t* orients, int n_ord, int n_ori, const double* H, const double* G,
-                            double* delta, hipStream_t s);
+struct WindowBatchEntry {      // one window of a batch (device array)
+    WindowDesc w;
+    int32_t p0, m;             // first position and number of bins of the window
+    int64_t g_off;             // offset of its m x m table in the batch's G buffer
+};
+void launch_p2_window_batch(const double* M2, int64_t ld2, const int32_t* pos2sel, int n, int k,
+                            const WindowBatchEntry* wb, int n_win, int max_m, const int8_t* orders, const uint8_t* orients,
+                            int n_ord, int n_ori, const double* H, double* G_all, double* delta_all, hipStream_t s);
 
 }  // namespace hicmi

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
                 }
             }
             ArgMin best = {__builtin_inf(), 0x7fffffff};
-#pragma unroll 4
+#pragma unroll 8
             for (int j = tid * 2; j < n; j += 2 * NN_THREADS) {     // ascending j per lane: strict '<' keeps the lowest index
                 double2 v = *reinterpret_cast<const double2*>(rowx + j);
                 uint32_t bits = smask[j >> 5] >> (j & 31);          // j even: both bits in one word; bits past n are 0
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
                     dd = d;
                 }
             }
-#pragma unroll 2
+#pragma unroll 4
             for (int j = tid * 2; j < n; j += 2 * NN_THREADS) {
                 double2 a = *reinterpret_cast<const double2*>(rx + j);
                 double2 b = *reinterpret_cast<const double2*>(ry + j);

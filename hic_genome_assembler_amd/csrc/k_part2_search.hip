@@ -187,6 +187,8 @@ void launch_p2_insert_delta(const double* M2, int64_t ld2, const int32_t* pos2se
 }
 
 // ---- window: G table ----------------------------------------------------------------------------
+// Windows are evaluated in BATCHES (blockIdx.y = window): within one round of scanOrdering most windows
+// bring no improvement, and until one does, all of them see the same arrangement.
 // block x = window bin at current position p0+x.  Its row of M2, restricted to the positions outside
 // [p0, p0+m), is staged through LDS in tiles; the 256 lanes form a 64 (slot t) x 4 (quarter of the
 // tile) grid, each lane keeping one accumulator per 64 slots, and the four quarters are added at
@@ -195,12 +197,17 @@ static constexpr int G_TILE = 2048;
 static constexpr int G_TMAX = 8;                        // up to 512 window bins per pass
 
 __global__ __launch_bounds__(256) void k_p2_window_G(const double* __restrict__ M2, int64_t ld2,
-                                                     const int32_t* __restrict__ pos2sel, int n, int p0, int m,
-                                                     const double* __restrict__ H, double* __restrict__ G)
+                                                     const int32_t* __restrict__ pos2sel, int n,
+                                                     const WindowBatchEntry* __restrict__ wb,
+                                                     const double* __restrict__ H, double* __restrict__ G_all)
 {
     __shared__ double vals[G_TILE];
     __shared__ double part[4][64];
+    const WindowBatchEntry& we = wb[blockIdx.y];
+    const int p0 = we.p0, m = we.m;
     const int x = blockIdx.x, tid = threadIdx.x, tl = tid & 63, seg = tid >> 6;
+    if (x >= m) return;
+    double* __restrict__ G = G_all + we.g_off;
     const double* __restrict__ row = M2 + (int64_t)pos2sel[p0 + x] * ld2;
     const double hn = H[n - 1];
     const int n_out = n - m;
@@ -243,24 +250,22 @@ __global__ __launch_bounds__(256) void k_p2_window_G(const double* __restrict__ 
     }
 }
 
-void launch_p2_window_G(const double* M2, int64_t ld2, const int32_t* pos2sel, int n, int p0, int m, const double* H,
-                        double* G, hipStream_t s)
-{
-    if (m <= 0) return;
-    hipLaunchKernelGGL(k_p2_window_G, dim3(m), dim3(256), 0, s, M2, ld2, pos2sel, n, p0, m, H, G);
-}
-
 // ---- window: per-candidate delta -----------------------------------------------------------------
-// block = candidate (order o, orientation r) of the k window scaffolds.  Slot j of the candidate holds
-// window scaffold jj = orders[o][j] laid down reversed iff orients[r][j]; a bin's window-local index
-// x is its offset inside the CURRENT window layout (that is how G is indexed).
-__global__ __launch_bounds__(64) void k_p2_window_delta(const double* __restrict__ M2, int64_t ld2, int n, int m, int k,
-                                                        WindowDesc w, const int8_t* __restrict__ orders,
+// block = (candidate, window).  Slot j of the candidate holds window scaffold jj = orders[o][j] laid
+// down reversed iff orients[r][j]; a bin's window-local index x is its offset inside the CURRENT
+// window layout (that is how G is indexed).
+__global__ __launch_bounds__(64) void k_p2_window_delta(const double* __restrict__ M2, int64_t ld2, int n, int k,
+                                                        const WindowBatchEntry* __restrict__ wb,
+                                                        const int8_t* __restrict__ orders,
                                                         const uint8_t* __restrict__ orients, int n_ori,
-                                                        const double* __restrict__ H, const double* __restrict__ G,
-                                                        double* __restrict__ delta)
+                                                        const double* __restrict__ H, const double* __restrict__ G_all,
+                                                        double* __restrict__ delta_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const WindowBatchEntry& we = wb[blockIdx.y];
+    const WindowDesc& w = we.w;
+    const int m = we.m;
+    const double* __restrict__ G = G_all + we.g_off;
     int32_t* useq = reinterpret_cast<int32_t*>(smem);          // selection index at slot t
     int32_t* xseq = useq + m;                                   // window-local index at slot t
     const int c = blockIdx.x, lane = threadIdx.x;
@@ -287,17 +292,20 @@ __global__ __launch_bounds__(64) void k_p2_window_delta(const double* __restrict
         for (int t = s + 1 + lane; t < m; t += 64) acc += row[useq[t]] * (hn - H[t - s - 1]);
     }
     acc = wave_sum_s(acc);
-    if (lane == 0) delta[c] = acc;
+    if (lane == 0) delta_all[(int64_t)blockIdx.y * gridDim.x + c] = acc;
 }
 
-void launch_p2_window_delta(const double* M2, int64_t ld2, int n, int m, int k, const WindowDesc& w, const int8_t* orders,
-                            const uint8_t* orients, int n_ord, int n_ori, const double* H, const double* G,
-                            double* delta, hipStream_t s)
+// one launch pair for n_win windows described by the device array wb; max_m = largest window (bins)
+void launch_p2_window_batch(const double* M2, int64_t ld2, const int32_t* pos2sel, int n, int k,
+                            const WindowBatchEntry* wb, int n_win, int max_m, const int8_t* orders, const uint8_t* orients,
+                            int n_ord, int n_ori, const double* H, double* G_all, double* delta_all, hipStream_t s)
 {
-    size_t lds = (((size_t)m * 2 * sizeof(int32_t)) + 15) & ~(size_t)15;
+    if (n_win <= 0 || max_m <= 0) return;
+    hipLaunchKernelGGL(k_p2_window_G, dim3(max_m, n_win), dim3(256), 0, s, M2, ld2, pos2sel, n, wb, H, G_all);
+    size_t lds = (((size_t)max_m * 2 * sizeof(int32_t)) + 15) & ~(size_t)15;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_window_delta), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_p2_window_delta, dim3(n_ord * n_ori), dim3(64), lds, s, M2, ld2, n, m, k, w, orders, orients, n_ori,
-                       H, G, delta);
+    hipLaunchKernelGGL(k_p2_window_delta, dim3(n_ord * n_ori, n_win), dim3(64), lds, s, M2, ld2, n, k, wb, orders, orients,
+                       n_ori, H, G_all, delta_all);
 }
 
 }  // namespace hicmi
