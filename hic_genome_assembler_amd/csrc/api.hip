@@ -95,6 +95,10 @@ struct hicmi_ctx {
     double* d_G = nullptr; int64_t g_cap = 0;
     double* d_delta = nullptr; int64_t delta_cap = 0;
     WindowBatchEntry* d_wb = nullptr; int64_t wb_cap = 0;
+    // pinned staging: pageable hipMemcpyAsync takes a slow, serialising path in the runtime, which hurts when
+    // several contexts are driven from different host threads
+    char* pin_up = nullptr; size_t pin_up_cap = 0, pin_up_off = 0;
+    char* pin_down = nullptr; size_t pin_down_cap = 0;
 
     // timing
     bool timing = false;
@@ -104,6 +108,8 @@ struct hicmi_ctx {
 };
 
 namespace {
+hipError_t sync_stream(hicmi_ctx* c);
+
 struct Timed {
     hicmi_ctx* c; int fam; hipEvent_t a = nullptr, b = nullptr;
     Timed(hicmi_ctx* ctx, int f, double algo_bytes) : c(ctx), fam(f)
@@ -129,13 +135,60 @@ struct Timed {
 int resolve_timing(hicmi_ctx* c)
 {
     if (c->regions.empty()) return HICMI_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     for (auto& r : c->regions) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) c->ms[r.fam] += ms;
         c->pool.push_back(r.a); c->pool.push_back(r.b);
     }
     c->regions.clear();
+    return HICMI_OK;
+}
+
+
+hipError_t sync_stream(hicmi_ctx* c)
+{
+    hipError_t e = hipStreamSynchronize(c->stream);
+    c->pin_up_off = 0;                                   // everything staged for upload has been consumed
+    return e;
+}
+
+// copy `bytes` from pageable host memory to the device through the pinned upload arena (asynchronous)
+int upload(hicmi_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return HICMI_OK;
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (c->pin_up_off + need > c->pin_up_cap) {
+        HIPCHK(sync_stream(c));
+        if (need > c->pin_up_cap) {
+            if (c->pin_up) (void)hipHostFree(c->pin_up);
+            c->pin_up = nullptr; c->pin_up_cap = 0;
+            size_t cap = std::max<size_t>(need * 2, (size_t)1 << 20);
+            HIPCHK(hipHostMalloc((void**)&c->pin_up, cap, hipHostMallocDefault));
+            c->pin_up_cap = cap;
+        }
+    }
+    char* slot = c->pin_up + c->pin_up_off;
+    memcpy(slot, src, bytes);
+    c->pin_up_off += need;
+    HIPCHK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
+    return HICMI_OK;
+}
+
+// device -> pageable host through the pinned download buffer; synchronises the stream
+int download(hicmi_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) { HIPCHK(sync_stream(c)); return HICMI_OK; }
+    if (bytes > c->pin_down_cap) {
+        if (c->pin_down) (void)hipHostFree(c->pin_down);
+        c->pin_down = nullptr; c->pin_down_cap = 0;
+        size_t cap = std::max<size_t>(bytes * 2, (size_t)1 << 20);
+        HIPCHK(hipHostMalloc((void**)&c->pin_down, cap, hipHostMallocDefault));
+        c->pin_down_cap = cap;
+    }
+    HIPCHK(hipMemcpyAsync(c->pin_down, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(sync_stream(c));
+    memcpy(dst, c->pin_down, bytes);
     return HICMI_OK;
 }
 
@@ -230,6 +283,8 @@ int hicmi_destroy(hicmi_ctx* c)
     free_dev(c->d_scaf_start); free_dev(c->d_scaf_len); free_dev(c->d_arr_packed);
     free_dev(c->d_pos2sel); free_dev(c->d_orders); free_dev(c->d_orients);
     free_dev(c->d_G); free_dev(c->d_delta); free_dev(c->d_wb);
+    if (c->pin_up) (void)hipHostFree(c->pin_up);
+    if (c->pin_down) (void)hipHostFree(c->pin_down);
     for (auto& r : c->regions) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
@@ -247,7 +302,7 @@ int hicmi_stream(hicmi_ctx* c, void** stream_out)
 int hicmi_synchronize(hicmi_ctx* c)
 {
     if (!c) return fail(HICMI_EINVAL, "NULL context");
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     return HICMI_OK;
 }
 
@@ -262,7 +317,7 @@ int hicmi_set_contacts_host(hicmi_ctx* c, const double* contacts, int64_t n)
     HIPCHK(hipMalloc((void**)&c->dC, sizeof(double) * (size_t)n * (size_t)n));
     c->own_c = true;
     HIPCHK(hipMemcpyAsync(c->dC, contacts, sizeof(double) * (size_t)n * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     return alloc_sums(c);
 }
 
@@ -292,7 +347,7 @@ int hicmi_row_sums(hicmi_ctx* c, double* np_sum, double* seq_sum)
     if (rc) return rc;
     if (np_sum) HIPCHK(hipMemcpyAsync(np_sum, c->d_np, sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
     if (seq_sum) HIPCHK(hipMemcpyAsync(seq_sum, c->d_seq, sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     return HICMI_OK;
 }
 
@@ -310,7 +365,7 @@ int hicmi_compact(hicmi_ctx* c, const int32_t* keep, int64_t n_keep)
     HIPCHK(hipMemcpyAsync(d_keep, keep, sizeof(int32_t) * (size_t)n_keep, hipMemcpyHostToDevice, c->stream));
     launch_compact(c->dC, c->ldc, d_keep, (int)n_keep, d_new, n_keep, c->stream);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     free_dev(d_keep);
     drop_matrix_state(c);
     c->dC = d_new; c->own_c = true; c->n = n_keep; c->ldc = n_keep;
@@ -331,7 +386,7 @@ int hicmi_selftest_division(hicmi_ctx* c, uint64_t seed, int64_t samples, uint64
     HIPCHK(hipGetLastError());
     unsigned long long bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, d, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     (void)hipFree(d);
     *mismatches_out = bad;
     return HICMI_OK;
@@ -435,7 +490,7 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
     int nn_state[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(nn_state, nnchain_state_ptr(c->d_size), sizeof(nn_state), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->zraw.data(), c->d_zraw, sizeof(double) * 4 * (size_t)(n - 1), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     if (getenv("HICMI_NNCHAIN_PROFILE")) {
         unsigned long long pr[5] = {0, 0, 0, 0, 0};
         HIPCHK(hipMemcpy(pr, nnchain_prof_ptr(c->d_size), sizeof(pr), hipMemcpyDeviceToHost));
@@ -500,7 +555,7 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
         launch_rank_invert(c->dR, c->dRank, ldr, (int)n, c->stream);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     c->have_rank = true;
     c->cached_start = -1;
     return HICMI_OK;
@@ -515,7 +570,7 @@ int hicmi_get_rank_rows(hicmi_ctx* c, int64_t row0, int64_t nrows, int inverse, 
     const uint16_t* src = (inverse ? c->dRank : c->dR) + row0 * c->ldr;
     HIPCHK(hipMemcpy2DAsync(out, sizeof(uint16_t) * (size_t)c->n, src, sizeof(uint16_t) * (size_t)c->ldr,
                             sizeof(uint16_t) * (size_t)c->n, (size_t)nrows, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     return HICMI_OK;
 }
 
@@ -530,7 +585,7 @@ int hicmi_get_similarity_row(hicmi_ctx* c, int64_t row, double* out)
     launch_similarity_row(c->dC, c->ldc, c->d_order, c->d_np, c->d_seq, (int)c->n, (int)row, c->d_tmp, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, c->d_tmp, sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     return HICMI_OK;
 }
 
@@ -570,7 +625,7 @@ int hicmi_cut_scan(hicmi_ctx* c, int64_t start, int64_t M, double psig, int32_t*
     HIPCHK(hipGetLastError());
     if (x_out) HIPCHK(hipMemcpyAsync(x_out, c->d_x, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
     if (sig_out) HIPCHK(hipMemcpyAsync(sig_out, c->d_sig, (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     return HICMI_OK;
 }
 
@@ -598,7 +653,7 @@ int hicmi_filter_scan(hicmi_ctx* c, int64_t start, int64_t cut, int64_t n_rows, 
     HIPCHK(hipGetLastError());
     if (x_out) HIPCHK(hipMemcpyAsync(x_out, c->d_x, sizeof(int32_t) * (size_t)n_rows, hipMemcpyDeviceToHost, c->stream));
     if (sig_out) HIPCHK(hipMemcpyAsync(sig_out, c->d_sig, (size_t)n_rows, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     return HICMI_OK;
 }
 
@@ -625,7 +680,7 @@ int hicmi_p2_select(hicmi_ctx* c, const int32_t* sel, int64_t n)
         rc = ensure(c->d_H, c->h_cap, n + 1);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(c->d_H, H.data(), sizeof(double) * (size_t)(n + 1), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(sync_stream(c));
     }
     HIPCHK(hipMemcpyAsync(c->d_sel, sel, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     {
@@ -633,7 +688,7 @@ int hicmi_p2_select(hicmi_ctx* c, const int32_t* sel, int64_t n)
         launch_p2_select(c->dC, c->ldc, c->d_sel, (int)n, c->dM2, ld2, c->stream);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     c->n2 = n; c->ld2 = ld2;
     c->n_scaf = 0; c->n_arr = 0; c->h_arr_id.clear();
     c->cache_valid = false; c->exact_cache.clear();
@@ -653,7 +708,7 @@ int hicmi_p2_total(hicmi_ctx* c, double* total_out)
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(total_out, c->d_partial + c->n2, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     return HICMI_OK;
 }
 
@@ -678,7 +733,7 @@ int hicmi_p2_score(hicmi_ctx* c, const int32_t* perms, int64_t n_cand, int64_t n
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(scores_out, c->d_scores, sizeof(double) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     return HICMI_OK;
 }
 
@@ -707,7 +762,7 @@ int hicmi_p2_score_exact(hicmi_ctx* c, const int32_t* perms, int64_t n_cand, int
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(scores_out, c->d_scores, sizeof(double) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     return HICMI_OK;
 }
 
@@ -733,7 +788,7 @@ int hicmi_p2_layout(hicmi_ctx* c, const int32_t* scaf_start, const int32_t* scaf
     c->n_scaf = n_scaf; c->n_arr = 0;
     HIPCHK(hipMemcpyAsync(c->d_scaf_start, scaf_start, sizeof(int32_t) * (size_t)n_scaf, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_scaf_len, scaf_len, sizeof(int32_t) * (size_t)n_scaf, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     return HICMI_OK;
 }
 
@@ -765,7 +820,8 @@ int hicmi_p2_set_arrangement(hicmi_ctx* c, const int32_t* ids, const uint8_t* re
     c->h_arr_packed.resize((size_t)(3 * S + 1));
     for (int64_t j = 0; j < S; j++) { c->h_arr_packed[(size_t)j] = ids[j]; c->h_arr_packed[(size_t)(2 * S + 1 + j)] = rev[j] ? 1 : 0; }
     for (int64_t j = 0; j <= S; j++) c->h_arr_packed[(size_t)(S + j)] = pos[(size_t)j];
-    HIPCHK(hipMemcpyAsync(c->d_arr_packed, c->h_arr_packed.data(), sizeof(int32_t) * (size_t)(3 * S + 1), hipMemcpyHostToDevice, c->stream));
+    rc = upload(c, c->d_arr_packed, c->h_arr_packed.data(), sizeof(int32_t) * (size_t)(3 * S + 1));
+    if (rc) return rc;
     launch_arr_materialize(c->d_arr_packed, (int)S, c->d_scaf_start, c->d_scaf_len, (int)c->n_arr, c->d_pos2sel, c->stream);
     HIPCHK(hipGetLastError());
     return HICMI_OK;
@@ -785,8 +841,8 @@ int hicmi_p2_arrangement_total(hicmi_ctx* c, double* total_out)
         launch_p2_total_perm(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, c->d_T, c->d_scores, c->stream);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(total_out, c->d_scores, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = download(c, total_out, c->d_scores, sizeof(double));
+    if (rc) return rc;
     return HICMI_OK;
 }
 
@@ -805,8 +861,8 @@ int hicmi_p2_arrangement_score(hicmi_ctx* c, double total, double* score_out)
     }
     HIPCHK(hipGetLastError());
     double part[NB];
-    HIPCHK(hipMemcpyAsync(part, c->d_scores, sizeof(double) * NB, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = download(c, part, c->d_scores, sizeof(double) * NB);
+    if (rc) return rc;
     double sum = 0.0;
     for (int b = 0; b < NB; b++) sum += part[b];
     *score_out = sum / total;
@@ -837,8 +893,8 @@ int hicmi_p2_score_insertions(hicmi_ctx* c, int32_t new_id, double total, double
     }
     HIPCHK(hipGetLastError());
     std::vector<double> host((size_t)n_out);
-    HIPCHK(hipMemcpyAsync(host.data(), c->d_scores, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = download(c, host.data(), c->d_scores, sizeof(double) * (size_t)n_out);
+    if (rc) return rc;
     double base = 0.0;
     for (int b = 0; b < NB; b++) base += host[(size_t)b];
     double straddle = 0.0;
@@ -862,7 +918,7 @@ int hicmi_p2_window_tables(hicmi_ctx* c, int64_t k, const int8_t* orders, int64_
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->d_orders, orders, (size_t)(n_orders * k), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_orients, orients, (size_t)(n_orients * k), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_stream(c));
     c->tab_k = (int)k; c->n_orders = n_orders; c->n_orients = n_orients;
     c->h_orders.assign(orders, orders + n_orders * k);
     c->h_orients.assign(orients, orients + n_orients * k);
@@ -906,7 +962,8 @@ int window_batch(hicmi_ctx* c, int64_t first0, int64_t count, int64_t k, double*
     if (rc) return rc;
     rc = ensure(c->d_wb, c->wb_cap, count);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(c->d_wb, wb.data(), sizeof(WindowBatchEntry) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    rc = upload(c, c->d_wb, wb.data(), sizeof(WindowBatchEntry) * (size_t)count);
+    if (rc) return rc;
     {
         // the G and delta kernels are launched as a pair; their algorithmic bytes are booked separately
         c->launches[F_P2_WINDOW_DELTA]++; c->bytes[F_P2_WINDOW_DELTA] += d_bytes;
@@ -915,8 +972,8 @@ int window_batch(hicmi_ctx* c, int64_t first0, int64_t count, int64_t k, double*
                                c->d_orients, (int)c->n_orders, (int)c->n_orients, c->d_H, c->d_G, c->d_delta, c->stream);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(delta_out, c->d_delta, sizeof(double) * (size_t)(n_cand * count), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = download(c, delta_out, c->d_delta, sizeof(double) * (size_t)(n_cand * count));
+    if (rc) return rc;
     return HICMI_OK;
 }
 }  // namespace
@@ -967,15 +1024,16 @@ int literal_scores(hicmi_ctx* c, const std::vector<std::vector<int32_t>>& rows, 
             if (rc) return rc;
             rc = ensure(c->d_T, c->t_cap, 2 * n_cand * n_used);
             if (rc) return rc;
-            HIPCHK(hipMemcpyAsync(c->d_perms, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice, c->stream));
+            rc = upload(c, c->d_perms, flat.data(), sizeof(int32_t) * flat.size());
+            if (rc) return rc;
             {
                 Timed t(c, F_P2_EXACT, 8.0 * (double)n_cand * 0.5 * (double)n_used * (double)(n_used - 1));
                 launch_p2_score_exact(c->dM2, c->ld2, c->d_perms, (int)n_cand, (int)n_used, total, c->d_T,
                                       c->d_T + n_cand * n_used, c->d_scores, c->stream);
             }
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(vals.data(), c->d_scores, sizeof(double) * vals.size(), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
+            rc = download(c, vals.data(), c->d_scores, sizeof(double) * vals.size());
+            if (rc) return rc;
         }
         for (size_t t = 0; t < todo.size(); t++) c->exact_cache[keys[todo[t]]] = vals[t];
     }
