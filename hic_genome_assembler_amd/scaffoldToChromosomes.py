@@ -158,20 +158,27 @@ def hyper_geom(x, M, n, N):
     return _lib.hypergeom_sf(x, M, n, N)
 
 
-def get_sliding_window_distance_metrics(input_array, window_size, global_index=0):
-    """S2C:370-411: left-half minus right-half window sums; 0 where the right half is short."""
+def _window_scores(input_array, window_size):
+    """break_sigs of S2C:390-400 as an int64 array (None for the ["NA","NA","NA"] case, S2C:380-381)."""
     if window_size >= len(input_array):
-        return ["NA", "NA", "NA"]
+        return None
     a = np.asarray(input_array, dtype=np.int64)
     h = int(window_size)
     cs = np.concatenate(([0], np.cumsum(a)))
-    k = np.arange(len(a) - h)
-    ok = k + 2 * h <= len(a)
-    scores = np.zeros(len(k), dtype=np.int64)
-    kk = k[ok]
-    scores[ok] = (cs[kk + h] - cs[kk]) - (cs[kk + 2 * h] - cs[kk + h])
+    scores = np.zeros(len(a) - h, dtype=np.int64)
+    full = max(0, len(a) - 2 * h + 1)                 # windows whose right half is complete; the rest score 0
+    if full:
+        scores[:full] = (cs[h:h + full] - cs[:full]) - (cs[2 * h:2 * h + full] - cs[h:h + full])
+    return scores
+
+
+def get_sliding_window_distance_metrics(input_array, window_size, global_index=0):
+    """S2C:370-411: left-half minus right-half window sums; 0 where the right half is short."""
+    scores = _window_scores(input_array, window_size)
+    if scores is None:
+        return ["NA", "NA", "NA"]
     best = int(np.flatnonzero(scores == scores.max())[0])
-    return [int(v) for v in scores], h, best
+    return [int(v) for v in scores], int(window_size), best
 
 
 def find_matrix_pvalue_breakpoints(argsorted_mat: RankMatrix, start, min_size, world_size, psig=.05):
@@ -193,10 +200,10 @@ def find_matrix_pvalue_breakpoints(argsorted_mat: RankMatrix, start, min_size, w
             break
         if loop_count >= 5:
             break
-    w = get_sliding_window_distance_metrics(sig, window_size=min_size)
-    if w[0] == "NA":
+    scores = _window_scores(sig, min_size)
+    if scores is None:
         return [], []
-    inds = [ii + min_size for ii, v in enumerate(w[0]) if v == min_size]
+    inds = [int(v) for v in np.flatnonzero(scores == min_size) + min_size]         # S2C:488
     return [min_size] * len(inds), inds
 
 
@@ -325,8 +332,8 @@ def assessClusterList(cList, scaffDict, outFile, percentToAssign=51.):
     """S2C:1001-1036: a scaffold joins the group holding >= 51 % of its bins and brings ALL its bins."""
     members = {}
     for line in cList:
-        cols = line.split("\t")
-        members.setdefault(cols[1], []).append(int(cols[0]))
+        bin_id, scaff = line.split("\t", 2)[:2]
+        members.setdefault(scaff, []).append(bin_id)
     final, assigned, false_pos = [], 0, 0
     outFile.write("#Scaffold\tNodesAssigend\tTotalNodes\tAssigned%\n")
     for s, nodes in members.items():
@@ -348,10 +355,10 @@ def assessChromosomeClustering(chromList, statsFile, percentToAssign=51.):
     all_nodes = [line for grp in chromList for line in grp]
     scaffolds = {}
     for line in all_nodes:
-        cols = line.split("\t")
-        scaffolds.setdefault(cols[1], []).append([int(cols[0]), cols[1]])
+        bin_id, scaff = line.split("\t", 2)[:2]
+        scaffolds.setdefault(scaff, []).append([int(bin_id), scaff])
     for s in scaffolds:
-        scaffolds[s] = sorted(scaffolds[s], key=lambda e: e[0])
+        scaffolds[s].sort(key=lambda e: e[0])
     final, false_pos, assigned = [], 0, 0
     with open(statsFile, "w") as fh:
         for k, grp in enumerate(chromList):
