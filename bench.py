@@ -151,7 +151,7 @@ def main():
         # (FETCH_SIZE, WRITE_SIZE; MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide coalesced read stream),
         # stored under profiles/: PMC collection cannot run inside the timed process.
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r1b_pmc_part1_16k.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r1c_pmc_part1_16k.json")
         pmc_kernel = {"nnchain": "hicmi::k_nn_epoch<false>", "sort_rows": "hicmi::k_sort_rows"}.get(fam)
         if n == 16000 and pmc_kernel and os.path.exists(pmc_file):
             with open(pmc_file) as fh:
@@ -160,7 +160,7 @@ def main():
             w_kb = pmc["WRITE_SIZE"].get(pmc_kernel)
             if f_kb and w_kb:
                 traffic = (2.0 * f_kb["sum_KB"] + w_kb["sum_KB"]) * 1024.0 / max(f_kb["dispatches"], 1)
-                traffic_src = "profiles/r1b_pmc_part1_16k.json (rocprofv3 --pmc passes, 2*FETCH_SIZE + WRITE_SIZE per dispatch)"
+                traffic_src = "profiles/r1c_pmc_part1_16k.json (rocprofv3 --pmc passes, 2*FETCH_SIZE + WRITE_SIZE per dispatch)"
         out = {
             "metric": "Part1+Part2 wall-clock (s) and bins/s on N x N contact map" if not args.part1_only
                       else "Part1 wall-clock (s) and bins/s on N x N contact map",
