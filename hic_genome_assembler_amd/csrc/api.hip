@@ -354,7 +354,7 @@ int hicmi_row_sums(hicmi_ctx* c, double* np_sum, double* seq_sum)
 int hicmi_compact(hicmi_ctx* c, const int32_t* keep, int64_t n_keep)
 {
     if (!c || !keep || n_keep < 1) return fail(HICMI_EINVAL, "bad arguments");
-    if (!c->dC || !c->own_c) return fail(HICMI_EINVAL, "hicmi_compact needs a matrix set with hicmi_set_contacts_host");
+    if (!c->dC) return fail(HICMI_EINVAL, "no contact matrix set");
     if (n_keep > c->n) return fail(HICMI_EINVAL, "n_keep > n");
     for (int64_t i = 0; i < n_keep; i++)
         if (keep[i] < 0 || keep[i] >= c->n || (i && keep[i] <= keep[i - 1])) return fail(HICMI_EINVAL, "keep must be ascending indices in [0, n)");

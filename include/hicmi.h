@@ -76,7 +76,8 @@ int hicmi_load_hicpro_matrix(const char *path, const int64_t *bin_ids, int64_t n
 int hicmi_row_sums(hicmi_ctx *ctx, double *np_sum, double *seq_sum);
 
 /* removeRows (S2C:100-136): keep only rows/columns keep[0..n_keep) (ascending); recomputes both
- * row sums on the compacted matrix.  Only valid for a matrix set with hicmi_set_contacts_host. */
+ * row sums on the compacted matrix.  The compacted copy is owned by the context (an adopted
+ * device matrix is left untouched). */
 int hicmi_compact(hicmi_ctx *ctx, const int32_t *keep, int64_t n_keep);
 
 /* ---- Part 1: clustering ---------------------------------------------------------------------
