@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
     __shared__ int s_i[16];
     __shared__ int ring[256];
     __shared__ double s_dprev;
-    __shared__ int s_tx2[2], s_tx, s_ty, s_ey;
+    __shared__ int s_x, s_prev, s_done, s_stop, s_mx, s_my, s_nx, s_ny, s_tx, s_ty, s_ey;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int step = w.state[0];
@@ -135,39 +135,35 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
     }
     for (int i = tid; i < nwords; i += NN_THREADS) { alive[i] = w.alive[i]; smask[i] = w.alive[i]; }
     for (int i = tid; i < n; i += NN_THREADS) { lsize[i] = w.size[i]; w.gtime[i] = -1; }
-    // Chain state is kept REDUNDANTLY in every lane (same values everywhere): the control flow is then
-    // uniform by construction and needs no broadcast barriers; only lane 0 writes shared/global state.
+    // lane-0 private chain state
     int len = w.state[1], top = w.state[2], second = w.state[3], first_ptr = w.state[4], ring_lo = len;
     unsigned long long t_book = 0, t_scan = 0, t_pick = 0, t_merge = 0, t_upd = 0, t0 = 0, t1 = 0;
-    if (tid == 0) { s_tx2[0] = -1; s_tx2[1] = -1; s_tx = -1; s_ty = -1; s_ey = -1; }
+    if (tid == 0) { s_stop = 0; s_done = 0; }
     __syncthreads();
-    int D = 0;                                              // dirty entries
-    int par = 0;                                            // parity of the scan counter (double-buffers s_tx2)
-    bool stop = false;
+    int D = 0;                                              // dirty entries (uniform across lanes)
+    uint32_t xbit = 0u;                                     // lane 0: the scan row's own bit in smask
 
     for (; step < total_steps && D < dcap; step++) {
         if (PROFILE && tid == 0) t0 = wall_clock64();
-        if (len == 0) {
+        if (tid == 0 && len == 0) {
             while (first_ptr < n && !((alive[first_ptr >> 5] >> (first_ptr & 31)) & 1u)) first_ptr++;
-            if (tid == 0) { chain[0] = first_ptr; ring[0] = first_ptr; }
-            ring_lo = 0; top = first_ptr; second = -1; len = 1;
+            chain[0] = first_ptr; ring[0] = first_ptr; ring_lo = 0; top = first_ptr; second = -1; len = 1;
         }
-        int guard = 0, x = 0, ybest = -1;
+        int guard = 0;
         double cur = 0.0;
+        int ybest = -1;
         while (true) {
-            x = top;
-            const int prev = (len > 1) ? second : -1;
-            uint32_t xbit = 0u;
             if (tid == 0) {
-                xbit = smask[x >> 5] & (1u << (x & 31));            // the row's own column is skipped by masking it
-                smask[x >> 5] &= ~xbit;
-                s_tx2[par ^ 1] = -1;                                  // ready for the next scan
+                s_x = top; s_prev = (len > 1) ? second : -1; s_tx = -1;
+                xbit = smask[top >> 5] & (1u << (top & 31));         // the row's own column is skipped by masking it
+                smask[top >> 5] &= ~xbit;
             }
-            if (tid < D && dslot[tid] == x) s_tx2[par] = dtime[tid];  // is the row itself dirty, and since when
+            __syncthreads();
+            const int x = s_x, prev = s_prev;
+            if (tid < D && dslot[tid] == x) s_tx = dtime[tid];       // is the row itself dirty, and since when
             __syncthreads();
             if (PROFILE && tid == 0) { t1 = wall_clock64(); t_book += t1 - t0; t0 = t1; }
-            const int tx = s_tx2[par];
-            par ^= 1;
+            const int tx = s_tx;
             const double* __restrict__ rowx = W + (int64_t)x * ld;
             // d(x, previous chain element) when that element is clean (a dirty one is handled below)
             if (tid == 64 && prev >= 0 && ((smask[prev >> 5] >> (prev & 31)) & 1u)) s_dprev = rowx[prev];
@@ -194,52 +190,60 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
             if (lane == 0) { s_v[wave] = best.v; s_i[wave] = best.i; }
             __syncthreads();
             if (PROFILE && tid == 0) { t1 = wall_clock64(); t_scan += t1 - t0; t0 = t1; }
-            // every wave finishes the reduction for itself: all lanes end up with the same (m, y, done)
-            ArgMin m = {lane < 16 ? s_v[lane] : __builtin_inf(), lane < 16 ? s_i[lane] : 0x7fffffff};
-            m = argmin_wave(m);
-            int y; double c;
-            if (prev >= 0) {
-                const double dprev = s_dprev;
-                if (m.v < dprev) { y = m.i; c = m.v; } else { y = prev; c = dprev; }
-            } else { y = m.i; c = m.v; }
-            bool done = (prev >= 0 && y == prev);
-            if (y < 0 || y >= n || ++guard > n + 2) { stop = true; done = true; }
-            if (tid == 0) smask[x >> 5] |= xbit;                    // un-mask the row's own column
-            if (!done) {
-                if (tid == 0) { chain[len] = y; ring[len & 255] = y; }
-                if (len - 255 > ring_lo) ring_lo = len - 255;
-                second = top; top = y; len++;
+            if (wave == 0) {
+                ArgMin m = {lane < 16 ? s_v[lane] : __builtin_inf(), lane < 16 ? s_i[lane] : 0x7fffffff};
+                m = argmin_wave(m);
+                if (lane == 0) {
+                    int y; double c;
+                    if (prev >= 0) {
+                        double dprev = s_dprev;
+                        if (m.v < dprev) { y = m.i; c = m.v; } else { y = prev; c = dprev; }
+                    } else { y = m.i; c = m.v; }
+                    int done = (prev >= 0 && y == prev);
+                    if (y < 0 || y >= n || ++guard > n + 2) { s_stop = 1; done = 1; }
+                    else if (!done) {
+                        chain[len] = y; ring[len & 255] = y;
+                        if (len - 255 > ring_lo) ring_lo = len - 255;
+                        second = top; top = y; len++;
+                    }
+                    cur = c; ybest = y;
+                    smask[x >> 5] |= xbit;                          // un-mask the row's own column
+                    s_done = done;
+                }
             }
-            cur = c; ybest = y;
+            __syncthreads();
             if (PROFILE && tid == 0) { t1 = wall_clock64(); t_pick += t1 - t0; t0 = t1; }
-            if (done) break;
+            if (s_done) break;
         }
-        if (stop) break;
-        // ---- merge: every lane derives the same (xx, yy, nx, ny); lane 0 records it
-        int mx = x, my = ybest;
-        if (mx > my) { int t = mx; mx = my; my = t; }
-        const int nx = lsize[mx], ny = lsize[my];
-        len -= 2;
+        if (s_stop) break;
         if (tid == 0) {
-            zraw[4 * (int64_t)step + 0] = (double)mx;
-            zraw[4 * (int64_t)step + 1] = (double)my;
+            int xx = s_x, yy = ybest;
+            len -= 2;
+            if (xx > yy) { int t = xx; xx = yy; yy = t; }
+            int nx = lsize[xx], ny = lsize[yy];
+            zraw[4 * (int64_t)step + 0] = (double)xx;
+            zraw[4 * (int64_t)step + 1] = (double)yy;
             zraw[4 * (int64_t)step + 2] = cur;
             zraw[4 * (int64_t)step + 3] = (double)(nx + ny);
-            alive[mx >> 5] &= ~(1u << (mx & 31));
-            smask[mx >> 5] &= ~(1u << (mx & 31));
+            lsize[xx] = 0;
+            lsize[yy] = (uint16_t)(nx + ny);
+            alive[xx >> 5] &= ~(1u << (xx & 31));
+            smask[xx >> 5] &= ~(1u << (xx & 31));
+            s_mx = xx; s_my = yy; s_nx = nx; s_ny = ny; s_tx = -1; s_ty = -1; s_ey = -1;
+            top = len >= 1 ? (len - 1 >= ring_lo ? ring[(len - 1) & 255] : chain[len - 1]) : -1;
+            second = len >= 2 ? (len - 2 >= ring_lo ? ring[(len - 2) & 255] : chain[len - 2]) : -1;
         }
+        __syncthreads();
+        const int mx = s_mx, my = s_my;
         if (tid < D) {
             if (dslot[tid] == mx) s_tx = dtime[tid];
             if (dslot[tid] == my) { s_ty = dtime[tid]; s_ey = tid; }
         }
-        __syncthreads();                                    // M1: masks, dirty times, and every lane has read nx, ny
-        if (tid == 0) { lsize[mx] = 0; lsize[my] = (uint16_t)(nx + ny); }
-        top = len >= 1 ? (len - 1 >= ring_lo ? ring[(len - 1) & 255] : chain[len - 1]) : -1;
-        second = len >= 2 ? (len - 2 >= ring_lo ? ring[(len - 2) & 255] : chain[len - 2]) : -1;
+        __syncthreads();
         if (PROFILE && tid == 0) { t1 = wall_clock64(); t_merge += t1 - t0; t0 = t1; }
         {
-            const int tmx = s_tx, tmy = s_ty, ey = s_ey;
-            const double fx = (double)nx, fy = (double)ny, fs = (double)(nx + ny);
+            const int tmx = s_tx, tmy = s_ty;
+            const double fx = (double)s_nx, fy = (double)s_ny, fs = (double)(s_nx + s_ny);
             const double rcp = 1.0 / fs;
             const double* __restrict__ rx = W + (int64_t)mx * ld;
             double* __restrict__ ry = W + (int64_t)my * ld;
@@ -264,20 +268,18 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
                 if ((bits & 2u) && j + 1 != my) b.y = div_by_small_int(fx * a.y + fy * b.y, fs, rcp);
                 *reinterpret_cast<double2*>(ry + j) = b;
             }
-            __syncthreads();                                // M2: row y rewritten, s_tx / s_ty / s_ey consumed
+            __syncthreads();
             if (dd >= 0) ry[dd] = dv;
             if (tid == 0) {                                 // cluster y is dirty from now on
-                if (ey >= 0) dslot[ey] = -1;                // its older entry is superseded
+                if (s_ey >= 0) dslot[s_ey] = -1;            // its older entry is superseded
                 dslot[D] = my; dtime[D] = step;
                 smask[my >> 5] &= ~(1u << (my & 31));
-                s_tx = -1; s_ty = -1; s_ey = -1;
             }
             D++;
         }
-        __syncthreads();                                    // M3: dirty list and masks visible to the next scan
+        __syncthreads();
         if (PROFILE && tid == 0) { t1 = wall_clock64(); t_upd += t1 - t0; }
     }
-    const int s_stop = stop ? 1 : 0;
     // ---- save state for the flush kernel and the next epoch
     __syncthreads();
     for (int i = tid; i < nwords; i += NN_THREADS) w.alive[i] = alive[i];
