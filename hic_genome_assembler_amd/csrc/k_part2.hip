@@ -119,9 +119,23 @@ __global__ __launch_bounds__(64) void k_p2_diag_sums(const double* __restrict__ 
             double r = 0.0;
             int o = 0, n = 0, lim = 0;
             if (l < nl) { o = leaf_off[l]; n = leaf_len[l]; lim = n - (n % 8); }
-            if (l < nl && n >= 8) {
-                r = elem(o + k);
-                for (int i = 8; i < lim; i += 8) r += elem(o + i + k);
+            {
+                // a leaf has at most 128 elements = 16 per lane: all index loads are issued together, then
+                // all matrix loads, and only the adds are serial (two memory round trips instead of 32)
+                int64_t idx[16];
+                double vals[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const bool ok = l < nl && n >= 8 && q * 8 < lim;
+                    const int t = o + q * 8 + k;
+                    const int a = ok ? (p ? p[t] : t) : 0, b = ok ? (p ? p[t + off] : t + off) : 0;
+                    idx[q] = (int64_t)a * ld2 + b;
+                }
+#pragma unroll
+                for (int q = 0; q < 16; q++) vals[q] = (l < nl && n >= 8 && q * 8 < lim) ? M2[idx[q]] : 0.0;
+                r = vals[0];
+#pragma unroll
+                for (int q = 1; q < 16; q++) if (q * 8 < lim) r += vals[q];
             }
             // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)): every lane of the wave takes part in the shuffles
             double s1 = r + __shfl_down(r, 1, 64);

@@ -39,6 +39,17 @@ __device__ __forceinline__ double block_sum_256(double v, double* s_w)
     return (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
+__device__ __forceinline__ double block_sum_1024(double v, double* s_w)      // s_w: 16 doubles
+{
+    v = wave_sum_s(v);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc += s_w[i];
+    return acc;
+}
+
 static size_t perm_lds_bytes(int n) { return (((size_t)n * sizeof(int32_t)) + 15) & ~(size_t)15; }
 
 // pos2sel[q] for the arrangement (arr_id, arr_rev) with prefix positions arr_pos[0..S]; the three
@@ -111,20 +122,20 @@ void launch_p2_base_partial(const double* M2, int64_t ld2, const int32_t* pos2se
 //   CROSS(g, r) = new-scaffold x arrangement pairs + pairs inside the new scaffold
 // STRADDLE(g+1) - STRADDLE(g) only involves the scaffold between the two gaps, so all gaps together
 // cost one pass over the sub-matrix instead of one pass per candidate.
-__global__ __launch_bounds__(256) void k_p2_insert_straddle(const double* __restrict__ M2, int64_t ld2,
+__global__ __launch_bounds__(1024) void k_p2_insert_straddle(const double* __restrict__ M2, int64_t ld2,
                                                             const int32_t* __restrict__ pos2sel, int n_arr,
                                                             const int32_t* __restrict__ arr_pos, int L,
                                                             const double* __restrict__ H, double* __restrict__ D)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t* p = reinterpret_cast<int32_t*>(smem);
-    __shared__ double s_w[4];
-    for (int q = threadIdx.x; q < n_arr; q += 256) p[q] = pos2sel[q];
+    __shared__ double s_w[16];
+    for (int q = threadIdx.x; q < n_arr; q += 1024) p[q] = pos2sel[q];
     __syncthreads();
     const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P0 = arr_pos[g], P1 = arr_pos[g + 1];
     double acc = 0.0;
-    for (int u = P0 + wave; u < P1; u += 4) {             // bins of the scaffold between gap g and g+1
+    for (int u = P0 + wave; u < P1; u += 16) {             // bins of the scaffold between gap g and g+1
         const double* __restrict__ row = M2 + (int64_t)p[u] * ld2;
 #pragma unroll 4
         for (int a = lane; a < P0; a += 64) {               // pairs (a, u) stop straddling
@@ -137,25 +148,25 @@ __global__ __launch_bounds__(256) void k_p2_insert_straddle(const double* __rest
             acc += row[p[b]] * (H[d + L - 1] - H[d - 1]);
         }
     }
-    double sum = block_sum_256(acc, s_w);
+    double sum = block_sum_1024(acc, s_w);
     if (threadIdx.x == 0) D[g] = sum;
 }
 
-__global__ __launch_bounds__(256) void k_p2_insert_cross(const double* __restrict__ M2, int64_t ld2,
+__global__ __launch_bounds__(1024) void k_p2_insert_cross(const double* __restrict__ M2, int64_t ld2,
                                                          const int32_t* __restrict__ pos2sel, int n_arr,
                                                          const int32_t* __restrict__ arr_pos, int new_start, int L,
                                                          const double* __restrict__ H, double* __restrict__ cross)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t* p = reinterpret_cast<int32_t*>(smem);
-    __shared__ double s_w[4];
-    for (int q = threadIdx.x; q < n_arr; q += 256) p[q] = pos2sel[q];
+    __shared__ double s_w[16];
+    for (int q = threadIdx.x; q < n_arr; q += 1024) p[q] = pos2sel[q];
     __syncthreads();
     const int g = blockIdx.x >> 1, r = blockIdx.x & 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P = arr_pos[g];
     const double hn = H[n_arr + L - 1];
     double acc = 0.0;
-    for (int e = wave; e < L; e += 4) {
+    for (int e = wave; e < L; e += 16) {
         const int xe = new_start + (r ? L - 1 - e : e);
         const double* __restrict__ row = M2 + (int64_t)xe * ld2;
 #pragma unroll 4
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(256) void k_p2_insert_cross(const double* __restric
             acc += row[x2] * (hn - H[e2 - e - 1]);
         }
     }
-    double sum = block_sum_256(acc, s_w);
+    double sum = block_sum_1024(acc, s_w);
     if (threadIdx.x == 0) cross[blockIdx.x] = sum;
 }
 
@@ -180,9 +191,9 @@ void launch_p2_insert_delta(const double* M2, int64_t ld2, const int32_t* pos2se
     launch_p2_base_partial(M2, ld2, pos2sel, n_arr, H, n_arr + L, n_base_blocks, out, s);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_insert_straddle), hipFuncAttributeMaxDynamicSharedMemorySize, (int)perm_lds_bytes(n_arr));
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_insert_cross), hipFuncAttributeMaxDynamicSharedMemorySize, (int)perm_lds_bytes(n_arr));
-    hipLaunchKernelGGL(k_p2_insert_straddle, dim3(S), dim3(256), lds, s, M2, ld2, pos2sel, n_arr, arr_pos, L, H,
+    hipLaunchKernelGGL(k_p2_insert_straddle, dim3(S), dim3(1024), lds, s, M2, ld2, pos2sel, n_arr, arr_pos, L, H,
                        out + n_base_blocks);
-    hipLaunchKernelGGL(k_p2_insert_cross, dim3(2 * (S + 1)), dim3(256), lds, s, M2, ld2, pos2sel, n_arr, arr_pos, new_start,
+    hipLaunchKernelGGL(k_p2_insert_cross, dim3(2 * (S + 1)), dim3(1024), lds, s, M2, ld2, pos2sel, n_arr, arr_pos, new_start,
                        L, H, out + n_base_blocks + S);
 }
 
