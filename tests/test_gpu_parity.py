@@ -400,6 +400,61 @@ def test_cli_drop_in(hic, tmp_path):
             assert fh.read() == gc.golden_text(name, fn), fn
 
 
+def test_part2_full_size_fixed_point_properties(hic, orc, tmp_path):
+    """Part 2 at the size of a BASELINE 16k-map chromosome (~1,500 bins, ~110 scaffolds), checked
+    through properties the oracle can afford: the final order is a fixed point of the sliding-window
+    search (no candidate of a window scores strictly above the final literal score), the literal score
+    of the final order is bit-identical between GPU and oracle, and fast vs literal scores agree."""
+    from hic_genome_assembler_amd import orderGenome as p2, synth
+    from hic_genome_assembler_amd.hostio import Bin
+    n = 1500
+    lay = synth.make_layout(n, seed=11, n_chrom=1, mean_scaffold_bins=13.0)
+    c = synth.dense_contacts(lay, seed=11, sinkhorn_iters=10)
+    bins = [Bin(int(lay.bin_ids[k]), lay.scaffold_names[lay.scaffold_of_bin[k]], 0, 0, 1.0, 0.) for k in range(n)]
+    group = [[b.ID, b.chrom] for b in bins]
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(c)
+        gm = p2.GenomeMatrix(ctx)
+        ordered = p2.orderChromosome(group, gm, bins, nScaffolds=6, scanScaffolds=5)
+        best = p2.orderChromosome.last_cost
+        view, _od = p2.giveNewAdjMat(gm, ordered, bins)
+        total = view.total()
+        ids, rev = view.layout.describe(ordered)
+        row = view.layout.node_row(ids, rev)
+        exact = ctx.p2_score_exact(row[None, :], total)[0]
+        fast = ctx.p2_score(row[None, :], total)[0]
+        # one more pass over every window must not find anything
+        view.layout.tables(5)
+        floor = max(best, exact)          # `total` is re-rounded for the final order: allow for that last bit
+        _i, _r, best2, _cf, improved = ctx.p2_scan_pass(ids, rev, 5, total, floor, None)
+        assert not improved and best2 == floor
+        # all 1920 candidates of two windows, literal scores on the oracle
+        orders, orients = p2._enumeration(5)
+        L = orc.lib()
+        sel_rows = view.layout.node_row(np.arange(len(view.layout.start)), np.zeros(len(view.layout.start), int))
+        sub_index = np.array([gm.bin_index(bins)[b] for s in sorted(view.layout.sid, key=view.layout.sid.get)
+                              for b in sorted(p2_scaffold_bins(ordered, s))])
+        sub = np.ascontiguousarray(c[np.ix_(sub_index, sub_index)])
+        assert len(sel_rows) == n
+        lit_final = L.hio_cost_literal(orc._dp(sub), n, orc._ip(row), n, total)
+        assert exact == lit_final
+        assert abs(fast - exact) <= 1e-11 * abs(exact)
+        assert abs(exact - best) <= 1e-12 * best              # same arrangement, totals rounded in different orders
+        for first in (0, len(ids) // 2):
+            fast_w, row_of = p2._window_scores(view, ordered, first, 5)
+            lit = np.array([L.hio_cost_literal(orc._dp(sub), n, orc._ip(np.ascontiguousarray(row_of(ci), dtype=np.int32)), n, total)
+                            for ci in range(len(fast_w))])
+            assert np.max(np.abs(fast_w - lit) / np.abs(lit)) < 1e-11
+            assert not np.any(lit > floor)                    # fixed point of scanOrdering
+
+
+def p2_scaffold_bins(ordered, name):
+    for s in ordered:
+        if s.name == name:
+            return s.binList
+    raise KeyError(name)
+
+
 # --------------------------------------------------------------------------------- BASELINE sizes: properties
 @pytest.mark.parametrize("n", [16000])
 def test_full_size_properties(hic, n):
