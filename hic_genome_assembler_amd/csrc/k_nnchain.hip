@@ -43,15 +43,49 @@ __device__ __forceinline__ double div_by_small_int(double num, double fs, double
     return fma(r, rcp, q);
 }
 
+// Lexicographic (value, index) minimum over the 64 lanes of a wave, result in every lane.  Inside a
+// row of 16 lanes the exchange is four DPP moves (quad swaps, half-row mirror, row mirror: register to
+// register, no LDS round trip like ds_bpermute); the four row results are read with v_readlane and
+// combined as scalars.  The minimum is exact whatever the order of the comparisons.
+template <int CTRL>
+__device__ __forceinline__ ArgMin argmin_dpp_step(ArgMin a)
+{
+    const int lo = __double2loint(a.v), hi = __double2hiint(a.v);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    const int oi = __builtin_amdgcn_update_dpp(a.i, a.i, CTRL, 0xf, 0xf, false);
+    const double ov = __hiloint2double(ohi, olo);
+    if (ov < a.v || (ov == a.v && oi < a.i)) { a.v = ov; a.i = oi; }
+    return a;
+}
+
+__device__ __forceinline__ ArgMin argmin_row16(ArgMin a)
+{
+    a = argmin_dpp_step<0xB1>(a);                          // quad_perm [1,0,3,2]
+    a = argmin_dpp_step<0x4E>(a);                          // quad_perm [2,3,0,1]
+    a = argmin_dpp_step<0x141>(a);                         // row_half_mirror
+    a = argmin_dpp_step<0x140>(a);                         // row_mirror
+    return a;
+}
+
+__device__ __forceinline__ ArgMin argmin_readlane(ArgMin a, int src)
+{
+    ArgMin r;
+    r.v = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a.v), src), __builtin_amdgcn_readlane(__double2loint(a.v), src));
+    r.i = __builtin_amdgcn_readlane(a.i, src);
+    return r;
+}
+
 __device__ __forceinline__ ArgMin argmin_wave(ArgMin a)
 {
+    a = argmin_row16(a);
+    ArgMin m = argmin_readlane(a, 0);
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double ov = __shfl_xor(a.v, off, 64);
-        int oi = __shfl_xor(a.i, off, 64);
-        if (ov < a.v || (ov == a.v && oi < a.i)) { a.v = ov; a.i = oi; }
+    for (int r = 16; r < 64; r += 16) {
+        const ArgMin o = argmin_readlane(a, r);
+        if (o.v < m.v || (o.v == m.v && o.i < m.i)) m = o;
     }
-    return a;
+    return m;
 }
 
 // workspace layout (all 16-byte aligned)
@@ -192,7 +226,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
             if (PROFILE && tid == 0) { t1 = wall_clock64(); t_scan += t1 - t0; t0 = t1; }
             if (wave == 0) {
                 ArgMin m = {lane < 16 ? s_v[lane] : __builtin_inf(), lane < 16 ? s_i[lane] : 0x7fffffff};
-                m = argmin_wave(m);
+                m = argmin_row16(m);                                // the 16 wave results sit in row 0
                 if (lane == 0) {
                     int y; double c;
                     if (prev >= 0) {
