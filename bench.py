@@ -16,6 +16,7 @@ N > 1: every rank processes its own map (independent genomes, no data-path colle
 """
 import argparse
 import contextlib
+import glob
 import io
 import json
 import os
@@ -124,7 +125,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.timing_enable(True)
+    ctx.timing_enable(not os.environ.get("HICMI_BENCH_NO_TIMING"))
     ctx.timing_reset()
     barrier()
     torch.cuda.synchronize()
@@ -151,7 +152,8 @@ def main():
         # (FETCH_SIZE, WRITE_SIZE; MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide coalesced read stream),
         # stored under profiles/: PMC collection cannot run inside the timed process.
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r1c_pmc_part1_16k.json")
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_part1_16k.json")))
+        pmc_file = pmc_files[-1] if pmc_files else ""             # the latest committed collection
         pmc_kernel = {"nnchain": "hicmi::k_nn_epoch<false>", "sort_rows": "hicmi::k_sort_rows"}.get(fam)
         if n == 16000 and pmc_kernel and os.path.exists(pmc_file):
             with open(pmc_file) as fh:
@@ -160,7 +162,8 @@ def main():
             w_kb = pmc["WRITE_SIZE"].get(pmc_kernel)
             if f_kb and w_kb:
                 traffic = (2.0 * f_kb["sum_KB"] + w_kb["sum_KB"]) * 1024.0 / max(f_kb["dispatches"], 1)
-                traffic_src = "profiles/r1c_pmc_part1_16k.json (rocprofv3 --pmc passes, 2*FETCH_SIZE + WRITE_SIZE per dispatch)"
+                traffic_src = ("profiles/%s (rocprofv3 --pmc passes, 2*FETCH_SIZE + WRITE_SIZE per dispatch)"
+                               % os.path.basename(pmc_file))
         out = {
             "metric": "Part1+Part2 wall-clock (s) and bins/s on N x N contact map" if not args.part1_only
                       else "Part1 wall-clock (s) and bins/s on N x N contact map",

@@ -46,6 +46,8 @@ static const char* kFamilyNames[F_COUNT] = {"row_sums", "build_w", "nnchain", "s
                                             "cut_count", "hyper_flags", "p2_select", "p2_total", "p2_score",
                                             "p2_score_exact", "p2_score_insert", "p2_window_G", "p2_window_delta"};
 
+constexpr int kBaseSlabs = 256;                        // partial sums of the closed-form BASE term (one slab per workgroup)
+
 struct TimedRegion { int fam; hipEvent_t a, b; };
 
 struct hicmi_ctx {
@@ -95,6 +97,13 @@ struct hicmi_ctx {
     double* d_G = nullptr; int64_t g_cap = 0;
     double* d_delta = nullptr; int64_t delta_cap = 0;
     WindowBatchEntry* d_wb = nullptr; int64_t wb_cap = 0;
+    // device-decided insertion (k_part2_insert.hip): second arrangement buffers (ping-pong) and work areas
+    int32_t* d_arr_packed2 = nullptr; int64_t arr2_cap = 0;
+    int32_t* d_pos2sel2 = nullptr; int64_t pos2_cap = 0;
+    double* d_ins_T = nullptr; int64_t ins_t_cap = 0;
+    double* d_ins_partial = nullptr; int64_t ins_partial_cap = 0;
+    int32_t* d_ins_perms = nullptr; int64_t ins_perms_cap = 0;
+    unsigned char* d_ins_blob = nullptr; int64_t ins_blob_cap = 0;   // [InsState][InsLog x steps]
     // pinned staging: pageable hipMemcpyAsync takes a slow, serialising path in the runtime, which hurts when
     // several contexts are driven from different host threads
     char* pin_up = nullptr; size_t pin_up_cap = 0, pin_up_off = 0;
@@ -283,6 +292,8 @@ int hicmi_destroy(hicmi_ctx* c)
     free_dev(c->d_scaf_start); free_dev(c->d_scaf_len); free_dev(c->d_arr_packed);
     free_dev(c->d_pos2sel); free_dev(c->d_orders); free_dev(c->d_orients);
     free_dev(c->d_G); free_dev(c->d_delta); free_dev(c->d_wb);
+    free_dev(c->d_arr_packed2); free_dev(c->d_pos2sel2); free_dev(c->d_ins_T); free_dev(c->d_ins_partial);
+    free_dev(c->d_ins_perms); free_dev(c->d_ins_blob);
     if (c->pin_up) (void)hipHostFree(c->pin_up);
     if (c->pin_down) (void)hipHostFree(c->pin_down);
     for (auto& r : c->regions) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -852,7 +863,7 @@ int hicmi_p2_arrangement_score(hicmi_ctx* c, double total, double* score_out)
     if (c->n_arr < 1) return fail(HICMI_EINVAL, "hicmi_p2_set_arrangement has not run");
     if (c->n_arr < 2) { *score_out = 0.0; return HICMI_OK; }
     HIPCHK(hipSetDevice(c->device));
-    const int NB = 64;
+    const int NB = kBaseSlabs;
     int rc = ensure(c->d_scores, c->scores_cap, NB);
     if (rc) return rc;
     {
@@ -881,7 +892,7 @@ int hicmi_p2_score_insertions(hicmi_ctx* c, int32_t new_id, double total, double
     if ((c->n_arr + new_len) * (int64_t)sizeof(int32_t) > 160 * 1024) return fail(HICMI_EUNSUPPORTED, "candidate longer than 40960 bins");
     HIPCHK(hipSetDevice(c->device));
     // incremental form: BASE (64 partial sums) - STRADDLE(g) (prefix sums of S increments) + CROSS(g, r)
-    const int NB = 64;
+    const int NB = kBaseSlabs;
     const int64_t n_out = NB + S + 2 * (S + 1);
     int rc = ensure(c->d_scores, c->scores_cap, n_out);
     if (rc) return rc;
@@ -1193,6 +1204,98 @@ int hicmi_p2_decide_insertion(hicmi_ctx* c, const int32_t* ids, const uint8_t* r
 
 // Whole loops of the search, so that a chromosome costs a handful of host calls (several chromosomes
 // run concurrently from host threads, each on its own context).
+namespace {
+void apply_insertion(int32_t* ids, uint8_t* rev, int64_t& S, int64_t gap, int32_t new_id, int32_t r)
+{
+    for (int64_t j = S; j > gap; j--) { ids[j] = ids[j - 1]; rev[j] = rev[j - 1]; }
+    ids[gap] = new_id; rev[gap] = (uint8_t)(r ? 1 : 0);
+    S++;
+}
+
+// Queue the insertion of new_ids[0..n_steps) with the decisions taken on the device (k_part2_insert.hip) and
+// synchronise once.  *done_out steps were decided and are applied to ids/rev/S; done < n_steps means the
+// device declined step `done` (short list longer than INS_MAXC) and the host has to decide it.
+int queue_insertions(hicmi_ctx* c, int32_t* ids, uint8_t* rev, int64_t& S, const int32_t* new_ids, int64_t n_steps,
+                     int64_t* done_out, double* best_out)
+{
+    *done_out = 0;
+    int rc = hicmi_p2_set_arrangement(c, ids, rev, S);
+    if (rc) return rc;
+    int64_t n_max = c->n_arr, S_max = S + n_steps;
+    for (int64_t t = 0; t < n_steps; t++) n_max += c->h_scaf_len[(size_t)new_ids[t]];
+    if (n_max * (int64_t)sizeof(int32_t) > 160 * 1024) return fail(HICMI_EUNSUPPORTED, "candidate longer than 40960 bins");
+    if (S_max + 1 > 8192) return HICMI_OK;                 // prefix table of k_ins_shortlist; the host path has no such limit
+    const int NB = kBaseSlabs;
+    static const int max_c = getenv("HICMI_P2_INS_MAXC") ? atoi(getenv("HICMI_P2_INS_MAXC")) : INS_MAXC;   // tests: force host steps
+    rc = ensure(c->d_arr_packed2, c->arr2_cap, 3 * std::max<int64_t>(S_max, c->n_scaf) + 2);
+    if (rc) return rc;
+    rc = ensure(c->d_pos2sel2, c->pos2_cap, c->n2);
+    if (rc) return rc;
+    rc = ensure(c->d_ins_T, c->ins_t_cap, (1 + 2 * (int64_t)INS_MAXC) * n_max);
+    if (rc) return rc;
+    rc = ensure(c->d_ins_partial, c->ins_partial_cap, NB + S_max + 2 * (S_max + 1));
+    if (rc) return rc;
+    rc = ensure(c->d_ins_perms, c->ins_perms_cap, (int64_t)INS_MAXC * n_max);
+    if (rc) return rc;
+    const size_t blob_bytes = sizeof(InsState) + sizeof(InsLog) * (size_t)n_steps;
+    rc = ensure(c->d_ins_blob, c->ins_blob_cap, (int64_t)blob_bytes);
+    if (rc) return rc;
+    InsState* st = reinterpret_cast<InsState*>(c->d_ins_blob);
+    InsLog* log = reinterpret_cast<InsLog*>(c->d_ins_blob + sizeof(InsState));
+    double* T_total = c->d_ins_T;
+    double* T_cand = c->d_ins_T + n_max;
+    double* work = c->d_ins_T + (1 + (int64_t)INS_MAXC) * n_max;
+    int32_t* packed[2] = {c->d_arr_packed, c->d_arr_packed2};
+    int32_t* pos2sel[2] = {c->d_pos2sel, c->d_pos2sel2};
+    {
+        double algo = 0.0;
+        int64_t na = c->n_arr;
+        for (int64_t t = 0; t < n_steps; t++) {
+            const double nn = (double)na, L = (double)c->h_scaf_len[(size_t)new_ids[t]], s = (double)(S + t);
+            algo += 8.0 * (0.5 * nn * (nn - 1.0) + nn * nn + 2.0 * (s + 1.0) * L * nn) + 4.0 * (nn + L) * (nn + L);
+            na += (int64_t)L;
+        }
+        Timed timed(c, F_P2_INSERT, algo);
+        launch_ins_reset(st, c->stream);
+        int64_t n_arr = c->n_arr;
+        for (int64_t t = 0; t < n_steps; t++) {
+            const int cur = (int)(t & 1), nxt = cur ^ 1;
+            const int32_t nid = new_ids[t];
+            const int st_new = c->h_scaf_start[(size_t)nid], L = c->h_scaf_len[(size_t)nid];
+            const int Sc = (int)(S + t), n_new = (int)(n_arr + L);
+            // literal total of "arrangement, then the new scaffold forward" (OG:484-487 -> OG:343)
+            launch_p2_diag_sums_ex(c->dM2, c->ld2, pos2sel[cur], 1, n_new, (int)n_arr, st_new, &st->fail, nullptr, T_total, c->stream);
+            launch_p2_insert_delta(c->dM2, c->ld2, pos2sel[cur], (int)n_arr, packed[cur] + Sc, Sc, st_new, L, c->d_H, NB,
+                                   c->d_ins_partial, c->stream, &st->fail);
+            launch_ins_shortlist(T_total, n_new, c->d_ins_partial, NB, Sc, (int)t, kNearTop, max_c, st, c->stream);
+            launch_ins_expand(pos2sel[cur], (int)n_arr, packed[cur] + Sc, st_new, L, st, c->d_ins_perms, c->stream);
+            launch_p2_diag_sums_ex(c->dM2, c->ld2, c->d_ins_perms, INS_MAXC, n_new, 0x7fffffff, 0, &st->fail, &st->n_short, T_cand,
+                                   c->stream);
+            launch_p2_cost_exact_ex(T_cand, INS_MAXC, n_new, &st->total, &st->fail, &st->n_short, work, st->lit, c->stream);
+            launch_ins_apply(pos2sel[cur], (int)n_arr, packed[cur], Sc, nid, st_new, L, st, packed[nxt], pos2sel[nxt], log + t,
+                             c->stream);
+            n_arr += L;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<unsigned char> blob(blob_bytes);
+    rc = download(c, blob.data(), c->d_ins_blob, blob_bytes);
+    if (rc) return rc;
+    const InsState* hst = reinterpret_cast<const InsState*>(blob.data());
+    const InsLog* hlog = reinterpret_cast<const InsLog*>(blob.data() + sizeof(InsState));
+    const int64_t done = hst->fail >= 0 ? std::min<int64_t>(hst->fail, n_steps) : n_steps;
+    for (int64_t t = 0; t < done; t++) {
+        if (hlog[t].gap < 0 || hlog[t].gap > S) return fail(HICMI_ESTATE, "insertion log out of range");
+        apply_insertion(ids, rev, S, hlog[t].gap, new_ids[t], hlog[t].rev);
+        *best_out = hlog[t].best;
+    }
+    *done_out = done;
+    // the device buffers hold a different arrangement from the host mirrors now
+    c->n_arr = 0; c->h_arr_id.clear(); c->h_arr_rev.clear(); c->h_arr_pos.clear(); c->h_pos2sel.clear();
+    return HICMI_OK;
+}
+}  // namespace
+
 int hicmi_p2_insert_all(hicmi_ctx* c, int32_t* ids, uint8_t* rev, int64_t S0, const int32_t* new_ids, int64_t n_new,
                         double* best_out)
 {
@@ -1201,16 +1304,32 @@ int hicmi_p2_insert_all(hicmi_ctx* c, int32_t* ids, uint8_t* rev, int64_t S0, co
     // orientation (it has never been flipped, OG:265) and leaves checkAllScores in the winning
     // orientation - '+' when nothing scored above 0 (OG:341, 367-368) - at the winning gap (0 by default).
     if (!c || !ids || !rev || !new_ids || !best_out || S0 < 1 || n_new < 1) return fail(HICMI_EINVAL, "bad arguments");
-    int64_t S = S0;
+    if (c->n_scaf < 1) return fail(HICMI_EINVAL, "hicmi_p2_layout has not run");
+    {
+        std::vector<uint8_t> used((size_t)c->n_scaf, 0);
+        for (int64_t j = 0; j < S0 + n_new; j++) {
+            const int32_t v = j < S0 ? ids[j] : new_ids[j - S0];
+            if (v < 0 || v >= c->n_scaf || used[(size_t)v]) return fail(HICMI_EINVAL, "scaffolds must be distinct members of the layout");
+            used[(size_t)v] = 1;
+        }
+    }
+    static const bool host_only = getenv("HICMI_P2_HOST_INSERT") != nullptr;     // A/B switch: every step decided by the host
+    int64_t S = S0, t = 0;
     double best = 0.0;
-    for (int64_t t = 0; t < n_new; t++) {
+    while (t < n_new) {
+        if (!host_only) {
+            int64_t done = 0;
+            int rc = queue_insertions(c, ids, rev, S, new_ids + t, n_new - t, &done, &best);
+            if (rc) return rc;
+            t += done;
+            if (t >= n_new) break;
+        }
         int64_t gap = -1; int32_t r = 0;
         int rc = hicmi_p2_decide_insertion(c, ids, rev, S, new_ids[t], 0, &gap, &r, &best);
         if (rc) return rc;
         if (gap < 0) { gap = 0; r = 0; best = 0.0; }
-        for (int64_t j = S; j > gap; j--) { ids[j] = ids[j - 1]; rev[j] = rev[j - 1]; }
-        ids[gap] = new_ids[t]; rev[gap] = (uint8_t)(r ? 1 : 0);
-        S++;
+        apply_insertion(ids, rev, S, gap, new_ids[t], r);
+        t++;
     }
     *best_out = best;
     return HICMI_OK;

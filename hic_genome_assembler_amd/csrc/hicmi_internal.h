@@ -3,7 +3,77 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace hicmi {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when a launch needs more than any earlier one
+// (the call costs as much as a launch, and the search paths launch tens of thousands of kernels)
+inline void ensure_dynamic_lds(const void* func, std::atomic<int>& have, size_t bytes)
+{
+    if ((int)bytes > have.load(std::memory_order_relaxed)) {
+        (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        have.store((int)bytes, std::memory_order_relaxed);
+    }
+}
+
+// ---- strictly left-to-right fp64 chains over LDS (the reference's Python sum() / running sums cannot be
+// re-associated).  One lane runs them; the next 8 operands are fetched while the current 8 are added, so
+// the chain waits on the adder only.
+static constexpr int SERIAL_BATCH = 16;                 // operands in flight: 16 dependent fp64 adds cover an LDS round trip
+
+__device__ __forceinline__ double serial_sum_lds(const double* t, int from, int to, double acc)
+{
+    constexpr int B = SERIAL_BATCH;
+    int i = from;
+    if (i + B <= to) {
+        double a[B];
+#pragma unroll
+        for (int q = 0; q < B; q++) a[q] = t[i + q];
+        while (i + 2 * B <= to) {
+            double b[B];
+#pragma unroll
+            for (int q = 0; q < B; q++) b[q] = t[i + B + q];
+#pragma unroll
+            for (int q = 0; q < B; q++) acc += a[q];
+#pragma unroll
+            for (int q = 0; q < B; q++) a[q] = b[q];
+            i += B;
+        }
+#pragma unroll
+        for (int q = 0; q < B; q++) acc += a[q];
+        i += B;
+    }
+    for (; i < to; i++) acc += t[i];
+    return acc;
+}
+
+// t[i] <- acc + t[from] + ... + t[i] for i in [from, to), left to right
+__device__ __forceinline__ double serial_prefix_lds(double* t, int from, int to, double acc)
+{
+    constexpr int B = SERIAL_BATCH;
+    int i = from;
+    if (i + B <= to) {
+        double a[B];
+#pragma unroll
+        for (int q = 0; q < B; q++) a[q] = t[i + q];
+        while (i + 2 * B <= to) {
+            double b[B];
+#pragma unroll
+            for (int q = 0; q < B; q++) b[q] = t[i + B + q];
+#pragma unroll
+            for (int q = 0; q < B; q++) { acc += a[q]; t[i + q] = acc; }
+#pragma unroll
+            for (int q = 0; q < B; q++) a[q] = b[q];
+            i += B;
+        }
+#pragma unroll
+        for (int q = 0; q < B; q++) { acc += a[q]; t[i + q] = acc; }
+        i += B;
+    }
+    for (; i < to; i++) { acc += t[i]; t[i] = acc; }
+    return acc;
+}
 
 // ---- launchers (defined next to their kernels) --------------------------------------------------
 // k_part1.hip
@@ -43,6 +113,13 @@ void launch_p2_score(const double* M2, int64_t ld2, const int32_t* perms, int n_
 
 void launch_p2_total_perm(const double* M2, int64_t ld2, const int32_t* d_perm, int n, double* T, double* total,
                           hipStream_t s);
+// gated forms for work that is queued ahead of the decisions it depends on (k_part2_insert.hip):
+// a launch returns at once when gate[0] >= 0, and candidates >= n_active[0] are skipped.
+// Position t of a candidate is perms[t] for t < n_head and tail_start + (t - n_head) after that.
+void launch_p2_diag_sums_ex(const double* M2, int64_t ld2, const int32_t* perms, int n_cand, int n_used, int n_head,
+                            int tail_start, const int32_t* gate, const int32_t* n_active, double* T, hipStream_t s);
+void launch_p2_cost_exact_ex(const double* T, int n_cand, int n_used, const double* total_ptr, const int32_t* gate,
+                             const int32_t* n_active, double* work, double* scores, hipStream_t s);
 
 // k_part2_search.hip
 struct WindowDesc {            // the k <= 8 scaffolds of a window, passed to the kernel by value
@@ -54,9 +131,10 @@ struct WindowDesc {            // the k <= 8 scaffolds of a window, passed to th
 void launch_arr_materialize(const int32_t* packed, int S, const int32_t* scaf_start, const int32_t* scaf_len, int n_arr,
                             int32_t* pos2sel, hipStream_t s);
 void launch_p2_base_partial(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const double* H, int n_tot,
-                            int n_blocks, double* out, hipStream_t s);
+                            int n_blocks, double* out, hipStream_t s, const int32_t* gate = nullptr);
 void launch_p2_insert_delta(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const int32_t* arr_pos,
-                            int S, int new_start, int L, const double* H, int n_base_blocks, double* out, hipStream_t s);
+                            int S, int new_start, int L, const double* H, int n_base_blocks, double* out, hipStream_t s,
+                            const int32_t* gate = nullptr);
 struct WindowBatchEntry {      // one window of a batch (device array)
     WindowDesc w;
     int32_t p0, m;             // first position and number of bins of the window
@@ -65,5 +143,24 @@ struct WindowBatchEntry {      // one window of a batch (device array)
 void launch_p2_window_batch(const double* M2, int64_t ld2, const int32_t* pos2sel, int n, int k,
                             const WindowBatchEntry* wb, int n_win, int max_m, const int8_t* orders, const uint8_t* orients,
                             int n_ord, int n_ori, const double* H, double* G_all, double* delta_all, hipStream_t s);
+
+
+// k_part2_insert.hip: orderRemainderScaffolds with the per-step decisions taken on the device
+static constexpr int INS_MAXC = 8;       // candidates re-scored literally per step; more -> the host decides that step
+struct InsState {
+    int32_t fail;                        // -1, or the first step the device could not decide
+    int32_t n_short;                     // short-listed candidates of the current step
+    int32_t gap[INS_MAXC], rev[INS_MAXC], idx[INS_MAXC];   // idx = position in the reference's enumeration
+    double total;                        // literal total of the step (OG:343)
+    double lit[INS_MAXC];                // literal scores of the short list
+};
+struct InsLog { int32_t gap, rev; double best; };
+void launch_ins_reset(InsState* st, hipStream_t s);
+void launch_ins_shortlist(const double* T, int n_used, const double* partial, int n_base_blocks, int S, int step,
+                          double near_top, int max_c, InsState* st, hipStream_t s);   // max_c <= INS_MAXC
+void launch_ins_expand(const int32_t* pos2sel, int n_arr, const int32_t* arr_pos, int new_start, int L, const InsState* st,
+                       int32_t* perms, hipStream_t s);
+void launch_ins_apply(const int32_t* pos2sel_in, int n_arr, const int32_t* packed_in, int S, int new_id, int new_start,
+                      int L, const InsState* st, int32_t* packed_out, int32_t* pos2sel_out, InsLog* log_entry, hipStream_t s);
 
 }  // namespace hicmi

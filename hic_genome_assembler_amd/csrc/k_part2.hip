@@ -51,67 +51,77 @@ __device__ __forceinline__ double wave_sum(double v)
 // of leaf results are combined serially along NumPy's recursion tree.
 static constexpr int MAX_LEAVES = 64;                  // an 8192-element chunk splits into <= 64 leaves
 
-// leaves of NumPy's pairwise recursion over [off, off+len), in order
-__device__ __forceinline__ int enumerate_leaves(int off, int len, int* leaf_off, int* leaf_len)
+// Leaves of NumPy's pairwise recursion over [off, off+len), in order, with their depth in the
+// recursion tree.  The explicit stack lives in LDS (st_off/st_len/st_dep: 16 entries each): private
+// arrays indexed at run time would be spilled to scratch memory, a global-memory round trip per access.
+__device__ __forceinline__ int enumerate_leaves(int off, int len, int* leaf_off, int* leaf_len, int* leaf_dep,
+                                                int* st_off, int* st_len, int* st_dep)
 {
-    int st_off[16], st_len[16], sp = 0, n = 0;
-    st_off[0] = off; st_len[0] = len; sp = 1;
+    int sp = 1, n = 0;
+    st_off[0] = off; st_len[0] = len; st_dep[0] = 0;
     while (sp > 0) {
         sp--;
-        int o = st_off[sp], l = st_len[sp];
-        if (l <= 128) { leaf_off[n] = o; leaf_len[n] = l; n++; continue; }
+        const int o = st_off[sp], l = st_len[sp], d = st_dep[sp];
+        if (l <= 128) { leaf_off[n] = o; leaf_len[n] = l; leaf_dep[n] = d; n++; continue; }
         int n2 = l / 2;
         n2 -= n2 % 8;
-        st_off[sp] = o + n2; st_len[sp] = l - n2; sp++;          // right half (processed second)
-        st_off[sp] = o; st_len[sp] = n2; sp++;                    // left half
+        st_off[sp] = o + n2; st_len[sp] = l - n2; st_dep[sp] = d + 1; sp++;      // right half (processed second)
+        st_off[sp] = o; st_len[sp] = n2; st_dep[sp] = d + 1; sp++;                // left half
     }
     return n;
 }
 
-// combine the leaf sums (in order) along the same recursion tree: left + right at every split
-__device__ __forceinline__ double combine_leaves(int len, const double* leaf_sum)
+// left + right at every split of the same tree: leaves arrive in order; whenever the two newest partial
+// results sit at the same depth they are the two halves of one node (left first) and are replaced by
+// their sum one level up.  val/dep: LDS stacks of 16 entries.
+__device__ __forceinline__ double combine_leaves(int n_leaves, const double* leaf_sum, const int* leaf_dep, double* val,
+                                                 int* dep)
 {
-    struct Frame { int len, n2, stage; double left; };
-    Frame st[10];
-    int sp = 1, next = 0;
-    double ret = 0.0;
-    st[0] = {len, 0, 0, 0.0};
-    while (sp > 0) {
-        Frame& f = st[sp - 1];
-        if (f.len <= 128) { ret = leaf_sum[next++]; sp--; continue; }
-        if (f.stage == 0) {
-            int n2 = f.len / 2;
-            n2 -= n2 % 8;
-            f.n2 = n2; f.stage = 1;
-            st[sp++] = {n2, 0, 0, 0.0};
-        } else if (f.stage == 1) {
-            f.left = ret; f.stage = 2;
-            st[sp++] = {f.len - f.n2, 0, 0, 0.0};
-        } else { ret = f.left + ret; sp--; }
+    int sp = 0;
+    for (int l = 0; l < n_leaves; l++) {
+        double v = leaf_sum[l];
+        int d = leaf_dep[l];
+        while (sp > 0 && dep[sp - 1] == d) { v = val[sp - 1] + v; d--; sp--; }
+        val[sp] = v; dep[sp] = d; sp++;
     }
-    return ret;
+    return val[0];
 }
 
 // T[cand][off] for off = 1..n_used-1 (T[cand][0] unused).  perms == nullptr: the identity order.
+// Position t maps to perms[t] below n_head and to tail_start + (t - n_head) from there on (an
+// arrangement followed by one more scaffold, without materialising the joined list).  gate / n_active:
+// see hicmi_internal.h.
 __global__ __launch_bounds__(64) void k_p2_diag_sums(const double* __restrict__ M2, int64_t ld2,
                                                      const int32_t* __restrict__ perms, int n_used,
-                                                     double* __restrict__ T)
+                                                     double* __restrict__ T, int n_head, int tail_start,
+                                                     const int32_t* __restrict__ gate,
+                                                     const int32_t* __restrict__ n_active)
 {
-    __shared__ int leaf_off[MAX_LEAVES], leaf_len[MAX_LEAVES];
+    __shared__ int leaf_off[MAX_LEAVES], leaf_len[MAX_LEAVES], leaf_dep[MAX_LEAVES];
     __shared__ double leaf_sum[MAX_LEAVES];
-    __shared__ int s_nleaves;
-    const int cand = blockIdx.y, off = blockIdx.x + 1, lane = threadIdx.x, slot = lane >> 3, k = lane & 7;
-    const int32_t* __restrict__ p = perms ? perms + (int64_t)cand * n_used : nullptr;
+    __shared__ int s_nleaves, st_a[16], st_b[16], st_c[16];
+    __shared__ double st_v[16];
+    const int lane = threadIdx.x, slot = lane >> 3, k = lane & 7;
+    if (gate && gate[0] >= 0) return;
+    // with n_active the launch has one layer of workgroups and each walks the (few) active candidates:
+    // a layer per possible candidate would be mostly workgroups that start only to return
+    const int cand_end = n_active ? n_active[0] : blockIdx.y + 1;
+    // Workgroups go to the 8 XCDs round-robin.  Eight neighbouring diagonals read the same 64-byte lines of
+    // a row, so each XCD takes whole groups of 8 neighbours (one L2 sees a line once instead of all eight
+    // L2s pulling it across the fabric): within every 64 workgroups the "XCD" and "member" digits swap.
+    const int b = blockIdx.x;
+    const int off = ((((b >> 6) << 3) + (b & 7)) << 3) + ((b >> 3) & 7) + 1;
+    if (off >= n_used) return;
+    for (int cand = n_active ? 0 : blockIdx.y; cand < cand_end; cand++) {
+    const int32_t* __restrict__ p = perms ? perms + (int64_t)cand * (n_head < n_used ? n_head : n_used) : nullptr;
     const int len = n_used - off;
-    auto elem = [&](int t) -> double {
-        int a = p ? p[t] : t, b = p ? p[t + off] : t + off;
-        return M2[(int64_t)a * ld2 + b];
-    };
+    auto at = [&](int t) -> int { return t < n_head ? (p ? p[t] : t) : tail_start + (t - n_head); };
+    auto elem = [&](int t) -> double { return M2[(int64_t)at(t) * ld2 + at(t + off)]; };
     double acc = 0.0;                                   // chunk results accumulate left to right from 0.0
     for (int c0 = 0; c0 < len; c0 += 8192) {
         const int clen = len - c0 < 8192 ? len - c0 : 8192;
         __syncthreads();
-        if (lane == 0) s_nleaves = enumerate_leaves(c0, clen, leaf_off, leaf_len);
+        if (lane == 0) s_nleaves = enumerate_leaves(c0, clen, leaf_off, leaf_len, leaf_dep, st_a, st_b, st_c);
         __syncthreads();
         const int nl = s_nleaves;
         for (int l0 = 0; l0 < nl; l0 += 8) {
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(64) void k_p2_diag_sums(const double* __restrict__ 
                 for (int q = 0; q < 16; q++) {
                     const bool ok = l < nl && n >= 8 && q * 8 < lim;
                     const int t = o + q * 8 + k;
-                    const int a = ok ? (p ? p[t] : t) : 0, b = ok ? (p ? p[t + off] : t + off) : 0;
+                    const int a = ok ? at(t) : 0, b = ok ? at(t + off) : 0;
                     idx[q] = (int64_t)a * ld2 + b;
                 }
 #pragma unroll
@@ -149,9 +159,10 @@ __global__ __launch_bounds__(64) void k_p2_diag_sums(const double* __restrict__ 
             }
         }
         __syncthreads();
-        if (lane == 0) acc += combine_leaves(clen, leaf_sum);
+        if (lane == 0) acc += combine_leaves(nl, leaf_sum, leaf_dep, st_v, st_a);
     }
     if (lane == 0) T[(int64_t)cand * n_used + off] = acc;
+    }
 }
 
 // The serial parts below are chains of dependent fp64 adds (the reference's order cannot be
@@ -169,10 +180,8 @@ __global__ __launch_bounds__(256) void k_p2_total_exact(const double* __restrict
     }
     if (threadIdx.x != 0) return;
     double acc = 0.0;                                   // Python sum(): 0 + T_1 + T_2 + ...
-    if (staged) {
-#pragma unroll 8
-        for (int i = 1; i < n_used; i++) acc += t[i];
-    } else {
+    if (staged) acc = serial_sum_lds(t, 1, n_used, 0.0);
+    else {
         for (int i = 1; i < n_used; i++) acc += T[i];
     }
     total[0] = acc;
@@ -181,10 +190,16 @@ __global__ __launch_bounds__(256) void k_p2_total_exact(const double* __restrict
 // one workgroup per candidate: the running sum of T and the final sum of the quotients are serial
 // (lane 0), the two divisions per offset are done by all lanes in between.
 __global__ __launch_bounds__(256) void k_p2_cost_exact(const double* __restrict__ T, int n_used, double total,
-                                                       double* __restrict__ work, double* __restrict__ scores)
+                                                       double* __restrict__ work, double* __restrict__ scores,
+                                                       const double* __restrict__ total_ptr,
+                                                       const int32_t* __restrict__ gate,
+                                                       const int32_t* __restrict__ n_active)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
     const int cand = blockIdx.x;
+    if (gate && gate[0] >= 0) return;
+    if (n_active && cand >= n_active[0]) return;
+    if (total_ptr) total = total_ptr[0];
     const double* __restrict__ tg = T + (int64_t)cand * n_used;
     const bool staged = n_used <= SERIAL_LDS_MAX;
     double* w = staged ? reinterpret_cast<double*>(smem_c) : work + (int64_t)cand * n_used;
@@ -194,10 +209,8 @@ __global__ __launch_bounds__(256) void k_p2_cost_exact(const double* __restrict_
     }
     if (threadIdx.x == 0) {
         double cum = 0.0;
-        if (staged) {
-#pragma unroll 8
-            for (int i = 1; i < n_used; i++) { cum += w[i]; w[i] = cum; }
-        } else {
+        if (staged) serial_prefix_lds(w, 1, n_used, 0.0);
+        else {
             for (int i = 1; i < n_used; i++) { cum += tg[i]; w[i] = cum; }
         }
     }
@@ -206,26 +219,31 @@ __global__ __launch_bounds__(256) void k_p2_cost_exact(const double* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         double cost = 0.0;
-#pragma unroll 8
-        for (int i = 1; i < n_used; i++) cost += w[i];
+        if (staged) cost = serial_sum_lds(w, 1, n_used, 0.0);
+        else for (int i = 1; i < n_used; i++) cost += w[i];
         scores[cand] = cost;
     }
 }
+
+static std::atomic<int> g_lds_total{0}, g_lds_cost{0}, g_lds_score{0};
+static constexpr int kNoTail = 0x7fffffff;
+static int diag_grid(int n_used) { return ((n_used - 1) + 63) & ~63; }     // see the index swap in k_p2_diag_sums
+static const int32_t* const kNoGate = nullptr;
 
 static size_t serial_lds_bytes(int n) { return n <= SERIAL_LDS_MAX ? (((size_t)n * sizeof(double)) + 15) & ~(size_t)15 : 16; }
 
 void launch_p2_total(const double* M2, int64_t ld2, int n, double* T, double* total, hipStream_t s)
 {
-    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(n - 1, 1), dim3(64), 0, s, M2, ld2, (const int32_t*)nullptr, n, T);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_total_exact), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n), 1), dim3(64), 0, s, M2, ld2, (const int32_t*)nullptr, n, T, kNoTail, 0, kNoGate, kNoGate);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_total_exact), g_lds_total, 65536);
     hipLaunchKernelGGL(k_p2_total_exact, dim3(1), dim3(256), serial_lds_bytes(n), s, T, n, total);
 }
 
 void launch_p2_total_perm(const double* M2, int64_t ld2, const int32_t* d_perm, int n, double* T, double* total,
                           hipStream_t s)
 {
-    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(n - 1, 1), dim3(64), 0, s, M2, ld2, d_perm, n, T);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_total_exact), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n), 1), dim3(64), 0, s, M2, ld2, d_perm, n, T, kNoTail, 0, kNoGate, kNoGate);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_total_exact), g_lds_total, 65536);
     hipLaunchKernelGGL(k_p2_total_exact, dim3(1), dim3(256), serial_lds_bytes(n), s, T, n, total);
 }
 
@@ -234,9 +252,27 @@ void launch_p2_score_exact(const double* M2, int64_t ld2, const int32_t* perms, 
                            double* T, double* work, double* scores, hipStream_t s)
 {
     if (n_cand <= 0) return;
-    if (n_used > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(n_used - 1, n_cand), dim3(64), 0, s, M2, ld2, perms, n_used, T);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_cost_exact), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    hipLaunchKernelGGL(k_p2_cost_exact, dim3(n_cand), dim3(256), serial_lds_bytes(n_used), s, T, n_used, total, work, scores);
+    if (n_used > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n_used), n_cand), dim3(64), 0, s, M2, ld2, perms, n_used, T, kNoTail, 0, kNoGate, kNoGate);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_cost_exact), g_lds_cost, 65536);
+    hipLaunchKernelGGL(k_p2_cost_exact, dim3(n_cand), dim3(256), serial_lds_bytes(n_used), s, T, n_used, total, work, scores,
+                       (const double*)nullptr, kNoGate, kNoGate);
+}
+
+void launch_p2_diag_sums_ex(const double* M2, int64_t ld2, const int32_t* perms, int n_cand, int n_used, int n_head,
+                            int tail_start, const int32_t* gate, const int32_t* n_active, double* T, hipStream_t s)
+{
+    if (n_cand <= 0 || n_used < 2) return;
+    hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n_used), n_active ? 1 : n_cand), dim3(64), 0, s, M2, ld2, perms, n_used, T,
+                       n_head, tail_start, gate, n_active);
+}
+
+void launch_p2_cost_exact_ex(const double* T, int n_cand, int n_used, const double* total_ptr, const int32_t* gate,
+                             const int32_t* n_active, double* work, double* scores, hipStream_t s)
+{
+    if (n_cand <= 0) return;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_cost_exact), g_lds_cost, 65536);
+    hipLaunchKernelGGL(k_p2_cost_exact, dim3(n_cand), dim3(256), serial_lds_bytes(n_used), s, T, n_used, 0.0, work, scores,
+                       total_ptr, gate, n_active);
 }
 
 // One workgroup (4 waves) per candidate.  Wave w takes rows a = w, w+4, ... of the candidate's
@@ -271,7 +307,7 @@ void launch_p2_score(const double* M2, int64_t ld2, const int32_t* perms, int n_
 {
     if (n_cand <= 0) return;
     size_t lds = (((size_t)n_used * sizeof(int32_t)) + 15) & ~(size_t)15;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_score), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_score), g_lds_score, lds);
     hipLaunchKernelGGL(k_p2_score, dim3(n_cand), dim3(256), lds, s, M2, ld2, perms, n_used, H, total, scores);
 }
 

@@ -85,11 +85,13 @@ void launch_arr_materialize(const int32_t* packed, int S, const int32_t* scaf_st
 __global__ __launch_bounds__(256) void k_p2_base_partial(const double* __restrict__ M2, int64_t ld2,
                                                          const int32_t* __restrict__ pos2sel, int n_arr,
                                                          const double* __restrict__ H, int n_tot,
-                                                         double* __restrict__ partial)
+                                                         double* __restrict__ partial,
+                                                         const int32_t* __restrict__ gate)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t* p = reinterpret_cast<int32_t*>(smem);
     __shared__ double s_w[4];
+    if (gate && gate[0] >= 0) return;
     for (int q = threadIdx.x; q < n_arr; q += 256) p[q] = pos2sel[q];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -105,12 +107,14 @@ __global__ __launch_bounds__(256) void k_p2_base_partial(const double* __restric
 }
 
 // BASE as partial sums over row slabs: out[0..n_blocks)
+static std::atomic<int> g_lds_base{0}, g_lds_straddle{0}, g_lds_cross{0}, g_lds_wdelta{0};
+
 void launch_p2_base_partial(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const double* H, int n_tot,
-                            int n_blocks, double* out, hipStream_t s)
+                            int n_blocks, double* out, hipStream_t s, const int32_t* gate)
 {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_base_partial), hipFuncAttributeMaxDynamicSharedMemorySize, (int)perm_lds_bytes(n_arr));
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_base_partial), g_lds_base, perm_lds_bytes(n_arr));
     hipLaunchKernelGGL(k_p2_base_partial, dim3(n_blocks), dim3(256), perm_lds_bytes(n_arr), s, M2, ld2, pos2sel, n_arr, H,
-                       n_tot, out);
+                       n_tot, out, gate);
 }
 
 // ---- insertion, incremental form ------------------------------------------------------------------
@@ -125,27 +129,30 @@ void launch_p2_base_partial(const double* M2, int64_t ld2, const int32_t* pos2se
 __global__ __launch_bounds__(1024) void k_p2_insert_straddle(const double* __restrict__ M2, int64_t ld2,
                                                             const int32_t* __restrict__ pos2sel, int n_arr,
                                                             const int32_t* __restrict__ arr_pos, int L,
-                                                            const double* __restrict__ H, double* __restrict__ D)
+                                                            const double* __restrict__ H, double* __restrict__ D,
+                                                            const int32_t* __restrict__ gate)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t* p = reinterpret_cast<int32_t*>(smem);
     __shared__ double s_w[16];
+    if (gate && gate[0] >= 0) return;
     for (int q = threadIdx.x; q < n_arr; q += 1024) p[q] = pos2sel[q];
     __syncthreads();
     const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P0 = arr_pos[g], P1 = arr_pos[g + 1];
+    const int len = P1 - P0, n_out = n_arr - len;
     double acc = 0.0;
     for (int u = P0 + wave; u < P1; u += 16) {             // bins of the scaffold between gap g and g+1
         const double* __restrict__ row = M2 + (int64_t)p[u] * ld2;
-#pragma unroll 4
-        for (int a = lane; a < P0; a += 64) {               // pairs (a, u) stop straddling
-            int d = u - a;
-            acc -= row[p[a]] * (H[d + L - 1] - H[d - 1]);
-        }
-#pragma unroll 4
-        for (int b = P1 + lane; b < n_arr; b += 64) {       // pairs (u, b) start straddling
-            int d = b - u;
-            acc += row[p[b]] * (H[d + L - 1] - H[d - 1]);
+        // positions before the scaffold: pairs (a, u) stop straddling; after it: pairs (u, b) start to
+#pragma unroll 8
+        for (int qq = lane; qq < n_out; qq += 64) {
+            const bool before = qq < P0;
+            const int pos = before ? qq : qq + len;
+            const int d = before ? u - pos : pos - u;
+            const double w = H[d + L - 1] - H[d - 1];
+            const double v = row[p[pos]] * w;
+            acc += before ? -v : v;
         }
     }
     double sum = block_sum_1024(acc, s_w);
@@ -155,11 +162,13 @@ __global__ __launch_bounds__(1024) void k_p2_insert_straddle(const double* __res
 __global__ __launch_bounds__(1024) void k_p2_insert_cross(const double* __restrict__ M2, int64_t ld2,
                                                          const int32_t* __restrict__ pos2sel, int n_arr,
                                                          const int32_t* __restrict__ arr_pos, int new_start, int L,
-                                                         const double* __restrict__ H, double* __restrict__ cross)
+                                                         const double* __restrict__ H, double* __restrict__ cross,
+                                                         const int32_t* __restrict__ gate)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t* p = reinterpret_cast<int32_t*>(smem);
     __shared__ double s_w[16];
+    if (gate && gate[0] >= 0) return;
     for (int q = threadIdx.x; q < n_arr; q += 1024) p[q] = pos2sel[q];
     __syncthreads();
     const int g = blockIdx.x >> 1, r = blockIdx.x & 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -184,17 +193,18 @@ __global__ __launch_bounds__(1024) void k_p2_insert_cross(const double* __restri
 }
 
 void launch_p2_insert_delta(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const int32_t* arr_pos,
-                            int S, int new_start, int L, const double* H, int n_base_blocks, double* out, hipStream_t s)
+                            int S, int new_start, int L, const double* H, int n_base_blocks, double* out, hipStream_t s,
+                            const int32_t* gate)
 {
     // out: [n_base_blocks partial sums of BASE][S straddle increments][2(S+1) cross terms]
     const size_t lds = perm_lds_bytes(n_arr);
-    launch_p2_base_partial(M2, ld2, pos2sel, n_arr, H, n_arr + L, n_base_blocks, out, s);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_insert_straddle), hipFuncAttributeMaxDynamicSharedMemorySize, (int)perm_lds_bytes(n_arr));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_insert_cross), hipFuncAttributeMaxDynamicSharedMemorySize, (int)perm_lds_bytes(n_arr));
+    launch_p2_base_partial(M2, ld2, pos2sel, n_arr, H, n_arr + L, n_base_blocks, out, s, gate);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_insert_straddle), g_lds_straddle, lds);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_insert_cross), g_lds_cross, lds);
     hipLaunchKernelGGL(k_p2_insert_straddle, dim3(S), dim3(1024), lds, s, M2, ld2, pos2sel, n_arr, arr_pos, L, H,
-                       out + n_base_blocks);
+                       out + n_base_blocks, gate);
     hipLaunchKernelGGL(k_p2_insert_cross, dim3(2 * (S + 1)), dim3(1024), lds, s, M2, ld2, pos2sel, n_arr, arr_pos, new_start,
-                       L, H, out + n_base_blocks + S);
+                       L, H, out + n_base_blocks + S, gate);
 }
 
 // ---- window: G table ----------------------------------------------------------------------------
@@ -314,7 +324,7 @@ void launch_p2_window_batch(const double* M2, int64_t ld2, const int32_t* pos2se
     if (n_win <= 0 || max_m <= 0) return;
     hipLaunchKernelGGL(k_p2_window_G, dim3(max_m, n_win), dim3(256), 0, s, M2, ld2, pos2sel, n, wb, H, G_all);
     size_t lds = (((size_t)max_m * 2 * sizeof(int32_t)) + 15) & ~(size_t)15;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_window_delta), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_window_delta), g_lds_wdelta, lds);
     hipLaunchKernelGGL(k_p2_window_delta, dim3(n_ord * n_ori, n_win), dim3(64), lds, s, M2, ld2, n, k, wb, orders, orients,
                        n_ori, H, G_all, delta_all);
 }

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import math
 import os
+import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -29,6 +30,7 @@ from . import _lib
 from .hostio import Bin, initiateLoci, read_contact_matrix  # noqa: F401
 
 SCORE_HOOK = None      # tests: called with the fast scores of every step, in enumeration order
+_PROFILE = bool(os.environ.get("HICMI_PART2_PROFILE"))   # per-chromosome wall clock on stderr
 WORKERS = int(os.environ.get("HICMI_PART2_WORKERS", "8"))   # chromosomes ordered concurrently (1 = sequential)
 NEAR_TOP = 1e-9        # relative band around a step's best fast score that is re-scored literally
 
@@ -611,13 +613,21 @@ def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds
     all reading the same device-resident contact matrix.  Results are collected in file order.
     Plots are not produced."""
     t0 = time.time()
+    t0p = time.perf_counter()
     n_workers = 1 if SCORE_HOOK is not None else max(1, min(WORKERS, len(chromList)))
     matrix.bin_index(binList)
 
     def one(i, m):
         print("#####################\n#####################")
         print("Working on Chr_" + str(i + 1) + "...")
-        return orderChromosome(chromList[i], m, binList, nScaffolds=nScaffolds, scanScaffolds=scanScaffolds)
+        if not _PROFILE:
+            return orderChromosome(chromList[i], m, binList, nScaffolds=nScaffolds, scanScaffolds=scanScaffolds)
+        ts = time.perf_counter()
+        res = orderChromosome(chromList[i], m, binList, nScaffolds=nScaffolds, scanScaffolds=scanScaffolds)
+        te = time.perf_counter()
+        sys.stderr.write("[hicmi] part2 chr %d: %d bins, %d scaffolds, start %.1f ms, %.1f ms\n"
+                         % (i + 1, len(chromList[i]), len(res), (ts - t0p) * 1e3, (te - ts) * 1e3))
+        return res
 
     if n_workers == 1 or not hasattr(matrix.ctx, "workers"):
         fullGenomeOrder = [one(i, matrix) for i in range(len(chromList))]

@@ -77,23 +77,21 @@ def removeRows(matrix: DeviceMatrix, binList, zeroRows=True, biasVals=False):
     """S2C:100-136: drop rows (and columns) whose NumPy row sum is 0, then store each bin's
     left-to-right row sum.  ``biasVals`` filtering is kept for signature compatibility."""
     np_sum, seq_sum = matrix.ctx.row_sums()
-    drop = []
-    for i in range(len(binList)):
-        if zeroRows is True and np_sum[i] == 0:
-            drop.append(i)
-            continue
-        if biasVals is not False and (binList[i].bias > biasVals[1] or binList[i].bias < biasVals[0]):
-            drop.append(i)
-    print("Rows/columns to remove " + str(len(drop)))
-    if drop:
-        gone = set(drop)
-        keep = [i for i in range(len(binList)) if i not in gone]
+    dropped = np.zeros(len(binList), dtype=bool)
+    if zeroRows is True:
+        dropped |= np.asarray(np_sum) == 0
+    if biasVals is not False:
+        bias = np.fromiter((b.bias for b in binList), dtype=np.float64, count=len(binList))
+        dropped |= ~dropped & ((bias > biasVals[1]) | (bias < biasVals[0]))
+    print("Rows/columns to remove " + str(int(dropped.sum())))
+    if dropped.any():
+        keep = np.flatnonzero(~dropped).tolist()
         matrix.ctx.compact(keep)
         binList = [binList[i] for i in keep]
         np_sum, seq_sum = matrix.ctx.row_sums()
     matrix.np_sum, matrix.seq_sum = np_sum, seq_sum
-    for b, v in zip(binList, seq_sum):
-        b.rowSum = float(v)
+    for b, v in zip(binList, np.asarray(seq_sum, dtype=np.float64).tolist()):
+        b.rowSum = v
     return matrix, binList
 
 
@@ -113,7 +111,7 @@ def averageClusterNodes(adjacencyMatrix: DeviceMatrix, nodeLabels, noPlot=True):
     t0 = time.time()
     leaves, z = adjacencyMatrix.ctx.upgma(want_linkage=True)
     print("Time to cluster " + str(time.time() - t0))
-    leaves = [int(v) for v in leaves]
+    leaves = np.asarray(leaves).tolist()
     return {"ivl": [nodeLabels[i] for i in leaves], "leaves": leaves, "Z": z}
 
 
@@ -292,13 +290,19 @@ def filter_noisy_breakpoints(argsorted_mat: RankMatrix, original_inds, psig=.05)
 
 # ------------------------------------------------------------------------------------------------
 def writeBinGroupingsToFile(coords, binList, outFile):
-    """S2C:945-964."""
+    """S2C:945-964.  Returns the groups as lists of the lines written (what
+    readBinGroupingsFromFile gives back for this file)."""
     bounds = [0] + [int(c) for c in coords] + [len(binList)]
+    groups, text = [], []
+    for g in range(len(bounds) - 1):
+        lines = ["\t".join((str(b.ID), b.chrom, str(b.start), str(b.stop), str(b.bias)))
+                 for b in binList[bounds[g]:bounds[g + 1]]]
+        text.append("### Chromosome group " + str(g + 1) + " ###\n")
+        text.extend(l + "\n" for l in lines)
+        groups.append(lines)
     with open(outFile, "w") as fh:
-        for g in range(len(bounds) - 1):
-            fh.write("### Chromosome group " + str(g + 1) + " ###\n")
-            for b in binList[bounds[g]:bounds[g + 1]]:
-                fh.write("\t".join((str(b.ID), b.chrom, str(b.start), str(b.stop), str(b.bias))) + "\n")
+        fh.write("".join(text))
+    return groups
 
 
 def readSizeFileToDict(sizeFile):
@@ -328,53 +332,65 @@ def readBinGroupingsFromFile(binGroupingsFile):
     return groups
 
 
-def assessClusterList(cList, scaffDict, outFile, percentToAssign=51.):
-    """S2C:1001-1036: a scaffold joins the group holding >= 51 % of its bins and brings ALL its bins."""
+def _assess_group(pairs, scaffDict, out, percentToAssign):
+    """assessClusterList on (bin, scaffold) pairs; ``out`` collects the report lines."""
     members = {}
-    for line in cList:
-        bin_id, scaff = line.split("\t", 2)[:2]
-        members.setdefault(scaff, []).append(bin_id)
+    for bin_id, scaff in pairs:
+        members[scaff] = members.get(scaff, 0) + 1
     final, assigned, false_pos = [], 0, 0
-    outFile.write("#Scaffold\tNodesAssigend\tTotalNodes\tAssigned%\n")
-    for s, nodes in members.items():
-        have, total = len(nodes), len(scaffDict[s])
+    out.append("#Scaffold\tNodesAssigend\tTotalNodes\tAssigned%\n")
+    for s, have in members.items():
+        total = len(scaffDict[s])
         pct = round(((float(have) / float(total)) * 100.), 2)
-        outFile.write(str(s) + "\t" + str(have) + "\t" + str(total) + "\t" + str(pct) + "%\n")
+        out.append(str(s) + "\t" + str(have) + "\t" + str(total) + "\t" + str(pct) + "%\n")
         if pct >= percentToAssign:
             final += scaffDict[s]
             assigned += 1
         else:
             false_pos += have
-    outFile.write("Total scaffolds clustered to chromosome " + str(len(members)) + "\n")
-    outFile.write("Total scaffolds assigned to chromosome " + str(assigned) + "\n")
+    out.append("Total scaffolds clustered to chromosome " + str(len(members)) + "\n")
+    out.append("Total scaffolds assigned to chromosome " + str(assigned) + "\n")
     return final, false_pos, assigned
 
 
+def _pairs_of_lines(cList):
+    return [tuple(line.split("\t", 2)[:2]) for line in cList]
+
+
+def assessClusterList(cList, scaffDict, outFile, percentToAssign=51.):
+    """S2C:1001-1036: a scaffold joins the group holding >= 51 % of its bins and brings ALL its bins."""
+    out = []
+    res = _assess_group(_pairs_of_lines(cList), scaffDict, out, percentToAssign)
+    outFile.write("".join(out))
+    return res
+
+
 def assessChromosomeClustering(chromList, statsFile, percentToAssign=51.):
-    """S2C:1038-1077."""
-    all_nodes = [line for grp in chromList for line in grp]
+    """S2C:1038-1077.  ``chromList``: groups of bin-grouping lines (``ID<TAB>scaffold<TAB>...``)."""
+    groups = [_pairs_of_lines(grp) for grp in chromList]
     scaffolds = {}
-    for line in all_nodes:
-        bin_id, scaff = line.split("\t", 2)[:2]
-        scaffolds.setdefault(scaff, []).append([int(bin_id), scaff])
-    for s in scaffolds:
-        scaffolds[s].sort(key=lambda e: e[0])
-    final, false_pos, assigned = [], 0, 0
+    for grp in groups:
+        for bin_id, scaff in grp:
+            scaffolds.setdefault(scaff, []).append(int(bin_id))
+    # every entry is [bin, scaffold], a scaffold's bins in ascending order
+    scaffolds = {s: [[b, s] for b in sorted(ids)] for s, ids in scaffolds.items()}
+    final, false_pos, assigned, out = [], 0, 0, []
+    for k, grp in enumerate(groups):
+        out.append("### Chromosome" + str(k + 1) + " ###\n")
+        nodes, fp, na = _assess_group(grp, scaffolds, out, percentToAssign)
+        if len(nodes) > 0:
+            final.append(nodes)
+        false_pos += fp
+        assigned += na
+        out.append("####################\n")
+    total = sum(len(grp) for grp in groups)
+    out.append("Total Nodes " + str(total) + "\n")
+    out.append("Properly clustered nodes " + str(total - false_pos) + "\n")
+    out.append("Falsely clustered nodes " + str(false_pos) + "\n")
+    out.append("Total scaffolds assigned to chromosomes " + str(assigned) + "\n")
+    out.append("Error rate ~" + str(round((float(false_pos) / float(total)) * 100., 2)) + "%\n")
     with open(statsFile, "w") as fh:
-        for k, grp in enumerate(chromList):
-            fh.write("### Chromosome" + str(k + 1) + " ###\n")
-            nodes, fp, na = assessClusterList(grp, scaffolds, fh, percentToAssign=percentToAssign)
-            if len(nodes) > 0:
-                final.append(nodes)
-            false_pos += fp
-            assigned += na
-            fh.write("####################\n")
-        total = len(all_nodes)
-        fh.write("Total Nodes " + str(total) + "\n")
-        fh.write("Properly clustered nodes " + str(total - false_pos) + "\n")
-        fh.write("Falsely clustered nodes " + str(false_pos) + "\n")
-        fh.write("Total scaffolds assigned to chromosomes " + str(assigned) + "\n")
-        fh.write("Error rate ~" + str(round((float(false_pos) / float(total)) * 100., 2)) + "%\n")
+        fh.write("".join(out))
     return final
 
 
@@ -382,11 +398,12 @@ def writeChromosomeGroupingsToFile(chromList, scaffSizeDict, outFile):
     """S2C:1079-1100: groups ordered by total scaffold bp, largest first (stable)."""
     sizes = [sum(scaffSizeDict[s] for s in {e[1]: '' for e in grp}) for grp in chromList]
     ranked = sorted(range(len(chromList)), key=lambda k: sizes[k], reverse=True)
+    text = []
+    for new_id, k in enumerate(ranked):
+        text.append("### Chromosome group " + str(new_id + 1) + " ###\n")
+        text.extend(str(e[0]) + "\t" + str(e[1]) + "\n" for e in chromList[k])
     with open(outFile, "w") as fh:
-        for new_id, k in enumerate(ranked):
-            fh.write("### Chromosome group " + str(new_id + 1) + " ###\n")
-            for e in chromList[k]:
-                fh.write(str(e[0]) + "\t" + str(e[1]) + "\n")
+        fh.write("".join(text))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -429,8 +446,8 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
     dendroLabels = [b.chrom + '_' + str(b.ID) for b in binList]
     dendrogram = averageClusterNodes(adjMat, dendroLabels, noPlot=True)
     dendrogramLeafOrder_toFile(dendrogram, dendrogramOrderFile)
-    dendoLeaves = readDengrogramLeavesFromFile(dendrogramOrderFile)
-    adjMat, binList = reorderMatrix(adjMat, binList, dendoLeaves['leaves'])
+    # the reference parses the file back (readDengrogramLeavesFromFile); the leaves are the same integers
+    adjMat, binList = reorderMatrix(adjMat, binList, dendrogram['leaves'])
     print("Total run-time to cluster = " + str(time.time() - t0))
     t0 = time.time()
     adjMat = convertMatrix(adjMat, binList, distance=False, similarity=True)
@@ -438,11 +455,11 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
     initial_cut_inds = pre_process_all_matrix_breakpoints(argsorted_adjMat, min_size=minSize,
                                                           min_frac=modularity, psig=psig)
     cutIndices = filter_noisy_breakpoints(argsorted_adjMat, initial_cut_inds, psig=psig)
-    writeBinGroupingsToFile(cutIndices, binList, binGroupFile)
+    binGroups = writeBinGroupingsToFile(cutIndices, binList, binGroupFile)
     print("Total run-time to identify chromosome boundaries = " + str(time.time() - t0))
     t0 = time.time()
     fastaSizeDict = readSizeFileToDict(hicProScaffSizeFile)
-    binGroups = readBinGroupingsFromFile(binGroupFile)
+    print(str(len(binGroups)) + " chromosomes read in from file")      # == readBinGroupingsFromFile(binGroupFile)
     chrGroups = assessChromosomeClustering(binGroups, assessmentFile)
     writeChromosomeGroupingsToFile(chrGroups, fastaSizeDict, chromosomeGroupFile)
     print("Total run-time to assign scaffolds to chromosomes = " + str(time.time() - t0))

@@ -1,0 +1,34 @@
+"""Sum a rocprofv3 --pmc counter per kernel: python summarize_pmc.py DIR_FETCH_SIZE DIR_WRITE_SIZE -> JSON.
+
+Each directory holds one `rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv` pass; the counter
+values of FETCH_SIZE / WRITE_SIZE are in KB (MI355X_MICROARCH.md, HBM section)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def summarize(directory):
+    files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
+    out = {}
+    seen = set()
+    for f in files:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                name = row["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+                d = out.setdefault(name, {"dispatches": 0, "sum_KB": 0.0})
+                key = (row["Dispatch_Id"], name)
+                if key not in seen:
+                    seen.add(key)
+                    d["dispatches"] += 1
+                d["sum_KB"] += float(row["Counter_Value"])
+    return dict(sorted(out.items()))
+
+
+if __name__ == "__main__":
+    res = {}
+    for directory in sys.argv[1:]:
+        counter = "FETCH_SIZE" if "FETCH" in os.path.basename(directory.rstrip("/")) else "WRITE_SIZE"
+        res[counter] = summarize(directory)
+    json.dump(res, sys.stdout, indent=1)

@@ -400,6 +400,33 @@ def test_cli_drop_in(hic, tmp_path):
             assert fh.read() == gc.golden_text(name, fn), fn
 
 
+@pytest.mark.parametrize("env", [{"HICMI_P2_HOST_INSERT": "1"}, {"HICMI_P2_INS_MAXC": "1"}],
+                         ids=["host-decides-every-step", "device-with-host-steps-on-ties"])
+def test_insertion_paths_agree(hic, tmp_path, env):
+    """orderRemainderScaffolds runs with the per-step decisions on the device (k_part2_insert.hip).  The same
+    golden files must come out when the host decides every step, and when the device's short list is capped
+    at one candidate so that every tie falls back to a host step in the middle of the queue (the switches
+    are read once per process, hence the subprocess)."""
+    import subprocess
+    import sys
+    from hic_genome_assembler_amd import synth
+    for name in ("n160", "n300_edges"):
+        spec, meta, gold, lay, c = gc.load_case(name)
+        work = tmp_path / name
+        work.mkdir()
+        paths = gc.write_case_files(name, str(work))
+        cfg = synth.write_config(str(work / "config.txt"), paths, str(work / "out"), str(work / "plots"),
+                                 lay.resolution, min_size=spec["min_size"], modularity=0.0, psig=spec["psig"],
+                                 n_scaffolds=spec["n_scaffolds"], scan_scaffolds=spec["scan_scaffolds"])
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        res = subprocess.run([sys.executable, os.path.join(root, "run_hicAssembler.py"), "-part1", "-part2", "-c", cfg],
+                             env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        for fn in gc.OUTPUT_FILES:
+            with open(str(work / "out" / fn)) as fh:
+                assert fh.read() == gc.golden_text(name, fn), (name, fn)
+
+
 def test_part2_full_size_fixed_point_properties(hic, orc, tmp_path):
     """Part 2 at the size of a BASELINE 16k-map chromosome (~1,500 bins, ~110 scaffolds), checked
     through properties the oracle can afford: the final order is a fixed point of the sliding-window

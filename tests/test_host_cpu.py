@@ -173,3 +173,31 @@ def test_part1_rejects_unimplemented_strategies(tmp_path):
         p1.runPipeline(*args, False, True, 5, 0.0, 20, .05, 5, .2, 100000)
     with pytest.raises(NotImplementedError):
         p1.runPipeline(*args, True, False, 5, 0.05, 20, .05, 5, .2, 100000)
+
+
+def test_intermediate_files_round_trip(tmp_path):
+    """runResident keeps the in-memory values instead of parsing its own intermediate files back (the
+    reference re-reads them, S2C:1124/1147): what the readers return for those files must be the same."""
+    from hic_genome_assembler_amd import scaffoldToChromosomes as s2c
+    from hic_genome_assembler_amd.hostio import Bin
+    rng = np.random.default_rng(5)
+    bins = [Bin(10 + i, "scaf%d" % (i // 7), 1000 * i, 1000 * (i + 1), float(rng.random()), 0.0) for i in range(60)]
+    dend = {"ivl": [b.chrom + "_" + str(b.ID) for b in bins], "leaves": rng.permutation(60).tolist()}
+    s2c.dendrogramLeafOrder_toFile(dend, str(tmp_path / "d.txt"))
+    back = s2c.readDengrogramLeavesFromFile(str(tmp_path / "d.txt"))
+    assert back["leaves"] == dend["leaves"] and back["ivl"] == dend["ivl"]
+    for cuts in ([], [9], [9, 30, 31]):
+        groups = s2c.writeBinGroupingsToFile(cuts, bins, str(tmp_path / "g.txt"))
+        assert s2c.readBinGroupingsFromFile(str(tmp_path / "g.txt")) == groups
+        assert sum(len(g) for g in groups) == 60 and len(groups) == len(cuts) + 1
+    # the voting report: per-group helper and whole-genome function agree with a direct restatement
+    groups = s2c.writeBinGroupingsToFile([9, 30], bins, str(tmp_path / "g.txt"))
+    final = s2c.assessChromosomeClustering(groups, str(tmp_path / "a.txt"))
+    sizes = {"scaf%d" % k: 7000 for k in range(9)}
+    s2c.writeChromosomeGroupingsToFile(final, sizes, str(tmp_path / "c.txt"))
+    kept = [int(l.split("\t")[0]) for l in open(tmp_path / "c.txt") if not l.startswith("#")]
+    # scaf1 has 2 of 7 bins in group 1 and 5 of 7 (71 %) in group 2; scaf4 2/7 vs 5/7: each joins one group once
+    assert sorted(kept) == [b.ID for b in bins]
+    report = open(tmp_path / "a.txt").read()
+    assert "scaf1\t2\t7\t28.57%" in report and "scaf1\t5\t7\t71.43%" in report
+    assert "Falsely clustered nodes 4" in report
