@@ -17,6 +17,8 @@ def summarize(directory):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+                if not name.startswith("hicmi::"):
+                    continue                      # the synthetic-map generator's torch kernels are not the product
                 d = out.setdefault(name, {"dispatches": 0, "sum_KB": 0.0})
                 key = (row["Dispatch_Id"], name)
                 if key not in seen:
