@@ -62,6 +62,7 @@ SIGNATURES = {
                                                  ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_int32),
                                                  ctypes.POINTER(c_dbl)]),
     "hicmi_p2_insert_all": (ctypes.c_int, [_vp, _vp, _vp, c_i64, _vp, c_i64, ctypes.POINTER(c_dbl)]),
+    "hicmi_p2_insert_all_multi": (ctypes.c_int, [c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hicmi_p2_scan_pass": (ctypes.c_int, [_vp, _vp, _vp, c_i64, c_i64, c_dbl, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl),
                                           ctypes.POINTER(ctypes.c_int32)]),
     "hicmi_timing_reset": (ctypes.c_int, [_vp]),
@@ -346,6 +347,33 @@ class Context:
         _check(self._lib.hicmi_p2_insert_all(self._h, _ptr(a), _ptr(b), s0, _ptr(nw), k, ctypes.byref(best)))
         self._arr_sig = None
         return a, b, best.value
+
+    @staticmethod
+    def p2_insert_all_multi(jobs):
+        """orderRemainderScaffolds for several chromosomes in lock step (hicmi_p2_insert_all_multi).
+        jobs: [(context, ids, rev, new_ids)], one distinct context per chromosome; returns
+        [(ids, rev, bestCost of the last insertion)] in the same order."""
+        n = len(jobs)
+        if n == 0:
+            return []
+        lib = jobs[0][0]._lib
+        keep, a_l, b_l, nw_l = [], [], [], []
+        for ctx, ids, rev, new_ids in jobs:
+            s0, k = len(ids), len(new_ids)
+            a = np.zeros(s0 + k, np.int32); a[:s0] = ids
+            b = np.zeros(s0 + k, np.uint8); b[:s0] = rev
+            a_l.append(a); b_l.append(b); nw_l.append(np.ascontiguousarray(new_ids, dtype=np.int32))
+        handles = (ctypes.c_void_p * n)(*[j[0]._h for j in jobs])
+        pa = (ctypes.c_void_p * n)(*[x.ctypes.data for x in a_l])
+        pb = (ctypes.c_void_p * n)(*[x.ctypes.data for x in b_l])
+        pn = (ctypes.c_void_p * n)(*[x.ctypes.data for x in nw_l])
+        s0s = (c_i64 * n)(*[len(j[1]) for j in jobs])
+        ks = (c_i64 * n)(*[len(j[3]) for j in jobs])
+        best = (c_dbl * n)()
+        _check(lib.hicmi_p2_insert_all_multi(n, handles, pa, pb, s0s, pn, ks, best))
+        for ctx, _i, _r, _n in jobs:
+            ctx._arr_sig = None
+        return [(a_l[j], b_l[j], best[j]) for j in range(n)]
 
     def p2_scan_pass(self, ids, rev, k, total, best, cur_fast):
         """One round of scanOrdering; returns (ids, rev, best, cur_fast, improved)."""

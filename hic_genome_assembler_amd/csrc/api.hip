@@ -102,8 +102,8 @@ struct hicmi_ctx {
     int32_t* d_pos2sel2 = nullptr; int64_t pos2_cap = 0;
     double* d_ins_T = nullptr; int64_t ins_t_cap = 0;
     double* d_ins_partial = nullptr; int64_t ins_partial_cap = 0;
-    int32_t* d_ins_perms = nullptr; int64_t ins_perms_cap = 0;
-    unsigned char* d_ins_blob = nullptr; int64_t ins_blob_cap = 0;   // [InsState][InsLog x steps]
+    unsigned char* d_ins_blob = nullptr; int64_t ins_blob_cap = 0;   // per job: [InsState][InsLog x steps]
+    InsStep* d_ins_steps = nullptr; int64_t ins_steps_cap = 0;       // [step][job] records of a lock-step queue
     // pinned staging: pageable hipMemcpyAsync takes a slow, serialising path in the runtime, which hurts when
     // several contexts are driven from different host threads
     char* pin_up = nullptr; size_t pin_up_cap = 0, pin_up_off = 0;
@@ -293,7 +293,7 @@ int hicmi_destroy(hicmi_ctx* c)
     free_dev(c->d_pos2sel); free_dev(c->d_orders); free_dev(c->d_orients);
     free_dev(c->d_G); free_dev(c->d_delta); free_dev(c->d_wb);
     free_dev(c->d_arr_packed2); free_dev(c->d_pos2sel2); free_dev(c->d_ins_T); free_dev(c->d_ins_partial);
-    free_dev(c->d_ins_perms); free_dev(c->d_ins_blob);
+    free_dev(c->d_ins_blob); free_dev(c->d_ins_steps);
     if (c->pin_up) (void)hipHostFree(c->pin_up);
     if (c->pin_down) (void)hipHostFree(c->pin_down);
     for (auto& r : c->regions) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -1212,86 +1212,180 @@ void apply_insertion(int32_t* ids, uint8_t* rev, int64_t& S, int64_t gap, int32_
     S++;
 }
 
-// Queue the insertion of new_ids[0..n_steps) with the decisions taken on the device (k_part2_insert.hip) and
-// synchronise once.  *done_out steps were decided and are applied to ids/rev/S; done < n_steps means the
-// device declined step `done` (short list longer than INS_MAXC) and the host has to decide it.
-int queue_insertions(hicmi_ctx* c, int32_t* ids, uint8_t* rev, int64_t& S, const int32_t* new_ids, int64_t n_steps,
-                     int64_t* done_out, double* best_out)
+struct InsJob {
+    hicmi_ctx* c; int32_t* ids; uint8_t* rev; int64_t S; const int32_t* new_ids; int64_t n_new;
+    int64_t t = 0; double best = 0.0; bool device_ok = true;
+};
+
+// Queue the remaining insertions of every job in lock step on `lead`'s stream, with the decisions taken on
+// the device (k_part2_insert.hip), and synchronise once.  Decided steps are applied to ids/rev/S/t of each
+// job; a job stops early at a step the device declined (short list longer than the cap), which the host
+// has to decide.
+int queue_insertions(hicmi_ctx* lead, const std::vector<InsJob*>& jobs)
 {
-    *done_out = 0;
-    int rc = hicmi_p2_set_arrangement(c, ids, rev, S);
-    if (rc) return rc;
-    int64_t n_max = c->n_arr, S_max = S + n_steps;
-    for (int64_t t = 0; t < n_steps; t++) n_max += c->h_scaf_len[(size_t)new_ids[t]];
-    if (n_max * (int64_t)sizeof(int32_t) > 160 * 1024) return fail(HICMI_EUNSUPPORTED, "candidate longer than 40960 bins");
-    if (S_max + 1 > 8192) return HICMI_OK;                 // prefix table of k_ins_shortlist; the host path has no such limit
+    const int nj = (int)jobs.size();
+    if (nj == 0) return HICMI_OK;
     const int NB = kBaseSlabs;
     static const int max_c = getenv("HICMI_P2_INS_MAXC") ? atoi(getenv("HICMI_P2_INS_MAXC")) : INS_MAXC;   // tests: force host steps
-    rc = ensure(c->d_arr_packed2, c->arr2_cap, 3 * std::max<int64_t>(S_max, c->n_scaf) + 2);
+    int64_t steps_max = 0;
+    std::vector<size_t> blob_off((size_t)nj);
+    size_t blob_bytes = 0;
+    for (int j = 0; j < nj; j++) {
+        InsJob& job = *jobs[(size_t)j];
+        hicmi_ctx* c = job.c;
+        int rc = hicmi_p2_set_arrangement(c, job.ids, job.rev, job.S);
+        if (rc) return rc;
+        if (c != lead) HIPCHK(sync_stream(c));             // the queue runs on lead's stream
+        const int64_t n_steps = job.n_new - job.t;
+        int64_t n_max = c->n_arr;
+        for (int64_t t = 0; t < n_steps; t++) n_max += c->h_scaf_len[(size_t)job.new_ids[job.t + t]];
+        if (n_max * (int64_t)sizeof(int32_t) > 160 * 1024) return fail(HICMI_EUNSUPPORTED, "candidate longer than 40960 bins");
+        const int64_t S_max = job.S + n_steps;
+        rc = ensure(c->d_arr_packed2, c->arr2_cap, 3 * std::max<int64_t>(S_max, c->n_scaf) + 2);
+        if (rc) return rc;
+        rc = ensure(c->d_pos2sel2, c->pos2_cap, c->n2);
+        if (rc) return rc;
+        rc = ensure(c->d_ins_T, c->ins_t_cap, (1 + 2 * (int64_t)INS_MAXC) * n_max);
+        if (rc) return rc;
+        rc = ensure(c->d_ins_partial, c->ins_partial_cap, NB + S_max + 2 * (S_max + 1));
+        if (rc) return rc;
+        steps_max = std::max(steps_max, n_steps);
+        blob_off[(size_t)j] = blob_bytes;
+        blob_bytes += (sizeof(InsState) + sizeof(InsLog) * (size_t)n_steps + 15) & ~(size_t)15;
+    }
+    HIPCHK(hipSetDevice(lead->device));
+    int rc = ensure(lead->d_ins_blob, lead->ins_blob_cap, (int64_t)blob_bytes);
     if (rc) return rc;
-    rc = ensure(c->d_pos2sel2, c->pos2_cap, c->n2);
+    rc = ensure(lead->d_ins_steps, lead->ins_steps_cap, steps_max * nj);
     if (rc) return rc;
-    rc = ensure(c->d_ins_T, c->ins_t_cap, (1 + 2 * (int64_t)INS_MAXC) * n_max);
-    if (rc) return rc;
-    rc = ensure(c->d_ins_partial, c->ins_partial_cap, NB + S_max + 2 * (S_max + 1));
-    if (rc) return rc;
-    rc = ensure(c->d_ins_perms, c->ins_perms_cap, (int64_t)INS_MAXC * n_max);
-    if (rc) return rc;
-    const size_t blob_bytes = sizeof(InsState) + sizeof(InsLog) * (size_t)n_steps;
-    rc = ensure(c->d_ins_blob, c->ins_blob_cap, (int64_t)blob_bytes);
-    if (rc) return rc;
-    InsState* st = reinterpret_cast<InsState*>(c->d_ins_blob);
-    InsLog* log = reinterpret_cast<InsLog*>(c->d_ins_blob + sizeof(InsState));
-    double* T_total = c->d_ins_T;
-    double* T_cand = c->d_ins_T + n_max;
-    double* work = c->d_ins_T + (1 + (int64_t)INS_MAXC) * n_max;
-    int32_t* packed[2] = {c->d_arr_packed, c->d_arr_packed2};
-    int32_t* pos2sel[2] = {c->d_pos2sel, c->d_pos2sel2};
-    {
-        double algo = 0.0;
-        int64_t na = c->n_arr;
-        for (int64_t t = 0; t < n_steps; t++) {
-            const double nn = (double)na, L = (double)c->h_scaf_len[(size_t)new_ids[t]], s = (double)(S + t);
-            algo += 8.0 * (0.5 * nn * (nn - 1.0) + nn * nn + 2.0 * (s + 1.0) * L * nn) + 4.0 * (nn + L) * (nn + L);
-            na += (int64_t)L;
-        }
-        Timed timed(c, F_P2_INSERT, algo);
-        launch_ins_reset(st, c->stream);
+    // one record per (step, job); sizes per step for the launch grids
+    std::vector<InsStep> table((size_t)(steps_max * nj));
+    std::vector<int> max_n_used((size_t)steps_max, 0), max_S((size_t)steps_max, 0), max_n_arr((size_t)steps_max, 0);
+    double algo = 0.0;
+    for (int j = 0; j < nj; j++) {
+        InsJob& job = *jobs[(size_t)j];
+        hicmi_ctx* c = job.c;
+        const int64_t n_steps = job.n_new - job.t;
+        int64_t n_max = c->n_arr;
+        for (int64_t t = 0; t < n_steps; t++) n_max += c->h_scaf_len[(size_t)job.new_ids[job.t + t]];
+        InsState* st = reinterpret_cast<InsState*>(lead->d_ins_blob + blob_off[(size_t)j]);
+        InsLog* log = reinterpret_cast<InsLog*>(lead->d_ins_blob + blob_off[(size_t)j] + sizeof(InsState));
+        int32_t* packed[2] = {c->d_arr_packed, c->d_arr_packed2};
+        int32_t* pos2sel[2] = {c->d_pos2sel, c->d_pos2sel2};
         int64_t n_arr = c->n_arr;
-        for (int64_t t = 0; t < n_steps; t++) {
+        for (int64_t t = 0; t < steps_max; t++) {
+            InsStep& d = table[(size_t)(t * nj + j)];
+            memset(&d, 0, sizeof(d));
+            d.st = st;
+            if (t >= n_steps) continue;                       // this chromosome has finished: inactive record
             const int cur = (int)(t & 1), nxt = cur ^ 1;
-            const int32_t nid = new_ids[t];
-            const int st_new = c->h_scaf_start[(size_t)nid], L = c->h_scaf_len[(size_t)nid];
-            const int Sc = (int)(S + t), n_new = (int)(n_arr + L);
-            // literal total of "arrangement, then the new scaffold forward" (OG:484-487 -> OG:343)
-            launch_p2_diag_sums_ex(c->dM2, c->ld2, pos2sel[cur], 1, n_new, (int)n_arr, st_new, &st->fail, nullptr, T_total, c->stream);
-            launch_p2_insert_delta(c->dM2, c->ld2, pos2sel[cur], (int)n_arr, packed[cur] + Sc, Sc, st_new, L, c->d_H, NB,
-                                   c->d_ins_partial, c->stream, &st->fail);
-            launch_ins_shortlist(T_total, n_new, c->d_ins_partial, NB, Sc, (int)t, kNearTop, max_c, st, c->stream);
-            launch_ins_expand(pos2sel[cur], (int)n_arr, packed[cur] + Sc, st_new, L, st, c->d_ins_perms, c->stream);
-            launch_p2_diag_sums_ex(c->dM2, c->ld2, c->d_ins_perms, INS_MAXC, n_new, 0x7fffffff, 0, &st->fail, &st->n_short, T_cand,
-                                   c->stream);
-            launch_p2_cost_exact_ex(T_cand, INS_MAXC, n_new, &st->total, &st->fail, &st->n_short, work, st->lit, c->stream);
-            launch_ins_apply(pos2sel[cur], (int)n_arr, packed[cur], Sc, nid, st_new, L, st, packed[nxt], pos2sel[nxt], log + t,
-                             c->stream);
+            const int32_t nid = job.new_ids[job.t + t];
+            const int L = c->h_scaf_len[(size_t)nid];
+            d.M2 = c->dM2; d.H = c->d_H; d.ld2 = c->ld2;
+            d.pos_cur = pos2sel[cur]; d.pos_nxt = pos2sel[nxt]; d.packed_cur = packed[cur]; d.packed_nxt = packed[nxt];
+            d.T_total = c->d_ins_T; d.T_cand = c->d_ins_T + n_max; d.work = c->d_ins_T + (1 + (int64_t)INS_MAXC) * n_max;
+            d.partial = c->d_ins_partial; d.log = log + t;
+            d.n_arr = (int32_t)n_arr; d.S = (int32_t)(job.S + t); d.L = L; d.new_start = c->h_scaf_start[(size_t)nid];
+            d.new_id = nid; d.active = 1; d.step = (int32_t)t;
+            max_n_used[(size_t)t] = std::max(max_n_used[(size_t)t], (int)(n_arr + L));
+            max_S[(size_t)t] = std::max(max_S[(size_t)t], d.S);
+            max_n_arr[(size_t)t] = std::max(max_n_arr[(size_t)t], (int)n_arr);
+            const double nn = (double)n_arr, Ld = (double)L, sd = (double)d.S;
+            algo += 8.0 * (0.5 * nn * (nn - 1.0) + nn * nn + 2.0 * (sd + 1.0) * Ld * nn) + 4.0 * (nn + Ld) * (nn + Ld);
             n_arr += L;
+        }
+    }
+    rc = upload(lead, lead->d_ins_steps, table.data(), sizeof(InsStep) * table.size());
+    if (rc) return rc;
+    {
+        Timed timed(lead, F_P2_INSERT, algo);
+        launch_insb_reset(lead->d_ins_steps, nj, lead->stream);
+        for (int64_t t = 0; t < steps_max; t++) {
+            const InsStep* st_t = lead->d_ins_steps + t * nj;
+            const int nu = max_n_used[(size_t)t];
+            launch_insb_diag_total(st_t, nj, nu, lead->stream);
+            launch_insb_fast(st_t, nj, max_S[(size_t)t], max_n_arr[(size_t)t], NB, lead->stream);
+            launch_insb_shortlist(st_t, nj, nu, max_S[(size_t)t], NB, kNearTop, max_c, lead->stream);
+            launch_insb_diag_cand(st_t, nj, nu, lead->stream);
+            launch_insb_cost(st_t, nj, nu, lead->stream);
+            launch_insb_apply(st_t, nj, nu, lead->stream);
         }
     }
     HIPCHK(hipGetLastError());
     std::vector<unsigned char> blob(blob_bytes);
-    rc = download(c, blob.data(), c->d_ins_blob, blob_bytes);
+    rc = download(lead, blob.data(), lead->d_ins_blob, blob_bytes);
     if (rc) return rc;
-    const InsState* hst = reinterpret_cast<const InsState*>(blob.data());
-    const InsLog* hlog = reinterpret_cast<const InsLog*>(blob.data() + sizeof(InsState));
-    const int64_t done = hst->fail >= 0 ? std::min<int64_t>(hst->fail, n_steps) : n_steps;
-    for (int64_t t = 0; t < done; t++) {
-        if (hlog[t].gap < 0 || hlog[t].gap > S) return fail(HICMI_ESTATE, "insertion log out of range");
-        apply_insertion(ids, rev, S, hlog[t].gap, new_ids[t], hlog[t].rev);
-        *best_out = hlog[t].best;
+    for (int j = 0; j < nj; j++) {
+        InsJob& job = *jobs[(size_t)j];
+        const int64_t n_steps = job.n_new - job.t;
+        const InsState* hst = reinterpret_cast<const InsState*>(blob.data() + blob_off[(size_t)j]);
+        const InsLog* hlog = reinterpret_cast<const InsLog*>(blob.data() + blob_off[(size_t)j] + sizeof(InsState));
+        const int64_t done = hst->fail >= 0 ? std::min<int64_t>(hst->fail, n_steps) : n_steps;
+        for (int64_t t = 0; t < done; t++) {
+            if (hlog[t].gap < 0 || hlog[t].gap > job.S) return fail(HICMI_ESTATE, "insertion log out of range");
+            apply_insertion(job.ids, job.rev, job.S, hlog[t].gap, job.new_ids[job.t + t], hlog[t].rev);
+            job.best = hlog[t].best;
+        }
+        job.t += done;
+        // the device buffers hold a different arrangement from the host mirrors now
+        hicmi_ctx* c = job.c;
+        c->n_arr = 0; c->h_arr_id.clear(); c->h_arr_rev.clear(); c->h_arr_pos.clear(); c->h_pos2sel.clear();
     }
-    *done_out = done;
-    // the device buffers hold a different arrangement from the host mirrors now
-    c->n_arr = 0; c->h_arr_id.clear(); c->h_arr_rev.clear(); c->h_arr_pos.clear(); c->h_pos2sel.clear();
+    return HICMI_OK;
+}
+
+int check_insert_job(const InsJob& job, int64_t S0)
+{
+    hicmi_ctx* c = job.c;
+    if (!c || !job.ids || !job.rev || !job.new_ids || S0 < 1 || job.n_new < 1) return fail(HICMI_EINVAL, "bad arguments");
+    if (c->n_scaf < 1) return fail(HICMI_EINVAL, "hicmi_p2_layout has not run");
+    std::vector<uint8_t> used((size_t)c->n_scaf, 0);
+    for (int64_t j = 0; j < S0 + job.n_new; j++) {
+        const int32_t v = j < S0 ? job.ids[j] : job.new_ids[j - S0];
+        if (v < 0 || v >= c->n_scaf || used[(size_t)v]) return fail(HICMI_EINVAL, "scaffolds must be distinct members of the layout");
+        used[(size_t)v] = 1;
+    }
+    return HICMI_OK;
+}
+
+int host_insertion_step(InsJob& job)
+{
+    int64_t gap = -1; int32_t r = 0;
+    int rc = hicmi_p2_decide_insertion(job.c, job.ids, job.rev, job.S, job.new_ids[job.t], 0, &gap, &r, &job.best);
+    if (rc) return rc;
+    if (gap < 0) { gap = 0; r = 0; job.best = 0.0; }
+    apply_insertion(job.ids, job.rev, job.S, gap, job.new_ids[job.t], r);
+    job.t++;
+    return HICMI_OK;
+}
+
+int run_insert_jobs(std::vector<InsJob>& all)
+{
+    static const bool host_only = getenv("HICMI_P2_HOST_INSERT") != nullptr;     // A/B switch: every step decided by the host
+    for (InsJob& job : all) {
+        int rc = check_insert_job(job, job.S);
+        if (rc) return rc;
+        if (job.S + job.n_new + 1 > 8192) job.device_ok = false;   // prefix table of k_insb_shortlist; the host path has no such limit
+    }
+    while (true) {
+        std::vector<InsJob*> todo;
+        for (InsJob& job : all) if (job.t < job.n_new && job.device_ok && !host_only) todo.push_back(&job);
+        if (!todo.empty()) {
+            int rc = queue_insertions(todo[0]->c, todo);
+            if (rc) return rc;
+        }
+        bool pending = false;
+        for (InsJob& job : all) {
+            if (job.t >= job.n_new) continue;
+            // the device declined this step (or may not be used): the host decides it
+            do {
+                int rc = host_insertion_step(job);
+                if (rc) return rc;
+            } while (job.t < job.n_new && (host_only || !job.device_ok));
+            if (job.t < job.n_new) pending = true;
+        }
+        if (!pending) break;
+    }
     return HICMI_OK;
 }
 }  // namespace
@@ -1303,35 +1397,31 @@ int hicmi_p2_insert_all(hicmi_ctx* c, int32_t* ids, uint8_t* rev, int64_t S0, co
     // on entry and S0 + n_new on return (capacity is the caller's).  Each new scaffold enters in '+'
     // orientation (it has never been flipped, OG:265) and leaves checkAllScores in the winning
     // orientation - '+' when nothing scored above 0 (OG:341, 367-368) - at the winning gap (0 by default).
-    if (!c || !ids || !rev || !new_ids || !best_out || S0 < 1 || n_new < 1) return fail(HICMI_EINVAL, "bad arguments");
-    if (c->n_scaf < 1) return fail(HICMI_EINVAL, "hicmi_p2_layout has not run");
-    {
-        std::vector<uint8_t> used((size_t)c->n_scaf, 0);
-        for (int64_t j = 0; j < S0 + n_new; j++) {
-            const int32_t v = j < S0 ? ids[j] : new_ids[j - S0];
-            if (v < 0 || v >= c->n_scaf || used[(size_t)v]) return fail(HICMI_EINVAL, "scaffolds must be distinct members of the layout");
-            used[(size_t)v] = 1;
-        }
+    if (!c || !best_out) return fail(HICMI_EINVAL, "bad arguments");
+    std::vector<InsJob> jobs(1);
+    jobs[0].c = c; jobs[0].ids = ids; jobs[0].rev = rev; jobs[0].S = S0; jobs[0].new_ids = new_ids; jobs[0].n_new = n_new;
+    int rc = run_insert_jobs(jobs);
+    if (rc) return rc;
+    *best_out = jobs[0].best;
+    return HICMI_OK;
+}
+
+int hicmi_p2_insert_all_multi(int64_t n_jobs, hicmi_ctx* const* ctxs, int32_t* const* ids, uint8_t* const* rev,
+                              const int64_t* S0, const int32_t* const* new_ids, const int64_t* n_new, double* best_out)
+{
+    // the same for several chromosomes (one context each, all on one device), advanced in lock step: one
+    // launch per kernel and step serves every chromosome that still has scaffolds to place
+    if (n_jobs < 1 || !ctxs || !ids || !rev || !S0 || !new_ids || !n_new || !best_out) return fail(HICMI_EINVAL, "bad arguments");
+    std::vector<InsJob> jobs((size_t)n_jobs);
+    for (int64_t j = 0; j < n_jobs; j++) {
+        InsJob& job = jobs[(size_t)j];
+        job.c = ctxs[j]; job.ids = ids[j]; job.rev = rev[j]; job.S = S0[j]; job.new_ids = new_ids[j]; job.n_new = n_new[j];
+        if (!job.c || job.c->device != ctxs[0]->device) return fail(HICMI_EINVAL, "contexts must share one device");
+        for (int64_t q = 0; q < j; q++) if (ctxs[q] == ctxs[j]) return fail(HICMI_EINVAL, "one context per chromosome");
     }
-    static const bool host_only = getenv("HICMI_P2_HOST_INSERT") != nullptr;     // A/B switch: every step decided by the host
-    int64_t S = S0, t = 0;
-    double best = 0.0;
-    while (t < n_new) {
-        if (!host_only) {
-            int64_t done = 0;
-            int rc = queue_insertions(c, ids, rev, S, new_ids + t, n_new - t, &done, &best);
-            if (rc) return rc;
-            t += done;
-            if (t >= n_new) break;
-        }
-        int64_t gap = -1; int32_t r = 0;
-        int rc = hicmi_p2_decide_insertion(c, ids, rev, S, new_ids[t], 0, &gap, &r, &best);
-        if (rc) return rc;
-        if (gap < 0) { gap = 0; r = 0; best = 0.0; }
-        apply_insertion(ids, rev, S, gap, new_ids[t], r);
-        t++;
-    }
-    *best_out = best;
+    int rc = run_insert_jobs(jobs);
+    if (rc) return rc;
+    for (int64_t j = 0; j < n_jobs; j++) best_out[j] = jobs[(size_t)j].best;
     return HICMI_OK;
 }
 

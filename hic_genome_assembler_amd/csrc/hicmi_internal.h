@@ -113,13 +113,6 @@ void launch_p2_score(const double* M2, int64_t ld2, const int32_t* perms, int n_
 
 void launch_p2_total_perm(const double* M2, int64_t ld2, const int32_t* d_perm, int n, double* T, double* total,
                           hipStream_t s);
-// gated forms for work that is queued ahead of the decisions it depends on (k_part2_insert.hip):
-// a launch returns at once when gate[0] >= 0, and candidates >= n_active[0] are skipped.
-// Position t of a candidate is perms[t] for t < n_head and tail_start + (t - n_head) after that.
-void launch_p2_diag_sums_ex(const double* M2, int64_t ld2, const int32_t* perms, int n_cand, int n_used, int n_head,
-                            int tail_start, const int32_t* gate, const int32_t* n_active, double* T, hipStream_t s);
-void launch_p2_cost_exact_ex(const double* T, int n_cand, int n_used, const double* total_ptr, const int32_t* gate,
-                             const int32_t* n_active, double* work, double* scores, hipStream_t s);
 
 // k_part2_search.hip
 struct WindowDesc {            // the k <= 8 scaffolds of a window, passed to the kernel by value
@@ -131,10 +124,9 @@ struct WindowDesc {            // the k <= 8 scaffolds of a window, passed to th
 void launch_arr_materialize(const int32_t* packed, int S, const int32_t* scaf_start, const int32_t* scaf_len, int n_arr,
                             int32_t* pos2sel, hipStream_t s);
 void launch_p2_base_partial(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const double* H, int n_tot,
-                            int n_blocks, double* out, hipStream_t s, const int32_t* gate = nullptr);
+                            int n_blocks, double* out, hipStream_t s);
 void launch_p2_insert_delta(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const int32_t* arr_pos,
-                            int S, int new_start, int L, const double* H, int n_base_blocks, double* out, hipStream_t s,
-                            const int32_t* gate = nullptr);
+                            int S, int new_start, int L, const double* H, int n_base_blocks, double* out, hipStream_t s);
 struct WindowBatchEntry {      // one window of a batch (device array)
     WindowDesc w;
     int32_t p0, m;             // first position and number of bins of the window
@@ -145,7 +137,8 @@ void launch_p2_window_batch(const double* M2, int64_t ld2, const int32_t* pos2se
                             int n_ord, int n_ori, const double* H, double* G_all, double* delta_all, hipStream_t s);
 
 
-// k_part2_insert.hip: orderRemainderScaffolds with the per-step decisions taken on the device
+// Lock-step insertion (k_part2_insert.hip): orderRemainderScaffolds for several chromosomes at once, every
+// decision taken on the device.  One InsStep per (step, chromosome), built by the host in advance.
 static constexpr int INS_MAXC = 8;       // candidates re-scored literally per step; more -> the host decides that step
 struct InsState {
     int32_t fail;                        // -1, or the first step the device could not decide
@@ -155,12 +148,22 @@ struct InsState {
     double lit[INS_MAXC];                // literal scores of the short list
 };
 struct InsLog { int32_t gap, rev; double best; };
-void launch_ins_reset(InsState* st, hipStream_t s);
-void launch_ins_shortlist(const double* T, int n_used, const double* partial, int n_base_blocks, int S, int step,
-                          double near_top, int max_c, InsState* st, hipStream_t s);   // max_c <= INS_MAXC
-void launch_ins_expand(const int32_t* pos2sel, int n_arr, const int32_t* arr_pos, int new_start, int L, const InsState* st,
-                       int32_t* perms, hipStream_t s);
-void launch_ins_apply(const int32_t* pos2sel_in, int n_arr, const int32_t* packed_in, int S, int new_id, int new_start,
-                      int L, const InsState* st, int32_t* packed_out, int32_t* pos2sel_out, InsLog* log_entry, hipStream_t s);
+struct InsStep {
+    const double* M2; const double* H; int64_t ld2;
+    const int32_t* pos_cur; int32_t* pos_nxt;            // arrangement as bin order (ping-pong)
+    const int32_t* packed_cur; int32_t* packed_nxt;       // [S ids][S+1 prefix positions][S reversed flags]
+    double *T_total, *T_cand, *work, *partial;
+    InsState* st; InsLog* log;                            // log: this step's entry
+    int32_t n_arr, S, L, new_start, new_id, active, step, pad;
+};
+// k_part2.hip / k_part2_search.hip / k_part2_insert.hip: one launch serves all chromosomes (blockIdx.y)
+void launch_insb_reset(const InsStep* steps, int n_chrom, hipStream_t s);
+void launch_insb_diag_total(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s);
+void launch_insb_fast(const InsStep* steps, int n_chrom, int max_S, int max_n_arr, int n_base_blocks, hipStream_t s);
+void launch_insb_shortlist(const InsStep* steps, int n_chrom, int max_n_used, int max_S, int n_base_blocks, double near_top,
+                           int max_c, hipStream_t s);
+void launch_insb_diag_cand(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s);
+void launch_insb_cost(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s);
+void launch_insb_apply(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s);
 
 }  // namespace hicmi

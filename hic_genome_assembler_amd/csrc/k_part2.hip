@@ -87,36 +87,38 @@ __device__ __forceinline__ double combine_leaves(int n_leaves, const double* lea
     return val[0];
 }
 
-// T[cand][off] for off = 1..n_used-1 (T[cand][0] unused).  perms == nullptr: the identity order.
-// Position t maps to perms[t] below n_head and to tail_start + (t - n_head) from there on (an
-// arrangement followed by one more scaffold, without materialising the joined list).  gate / n_active:
-// see hicmi_internal.h.
-__global__ __launch_bounds__(64) void k_p2_diag_sums(const double* __restrict__ M2, int64_t ld2,
-                                                     const int32_t* __restrict__ perms, int n_used,
-                                                     double* __restrict__ T, int n_head, int tail_start,
-                                                     const int32_t* __restrict__ gate,
-                                                     const int32_t* __restrict__ n_active)
+// Where position t of a candidate order sits in the selection: an index list with, optionally, one
+// scaffold (selection range [new_start, new_start + L), reversed or not) spliced in at position P - the
+// candidates of an insertion step are never materialised.  p == nullptr: the identity list.
+struct IndexMap {
+    const int32_t* p;
+    int P, L, new_start, rev;
+    __device__ __forceinline__ int at(int t) const
+    {
+        if (t < P) return p ? p[t] : t;
+        if (t - P < L) return new_start + (rev ? L - 1 - (t - P) : t - P);
+        return p ? p[t - L] : t - L;
+    }
+};
+static constexpr int kNoSplice = 0x7fffffff;
+
+// Workgroups go to the 8 XCDs round-robin.  Eight neighbouring diagonals read the same 64-byte lines of a
+// row, so each XCD takes whole groups of 8 neighbours (one L2 sees a line once instead of all eight L2s
+// pulling it across the fabric): within every 64 workgroups the "XCD" and "member" digits swap.
+__device__ __forceinline__ int diag_of_block(int b) { return ((((b >> 6) << 3) + (b & 7)) << 3) + ((b >> 3) & 7) + 1; }
+static int diag_grid(int n_used) { return ((n_used - 1) + 63) & ~63; }
+
+// numpy.trace(M_perm, offset=off) for one candidate, by one 64-lane workgroup; the result is returned in lane 0
+__device__ __forceinline__ double diag_sum_body(const double* __restrict__ M2, int64_t ld2, const IndexMap& m, int n_used,
+                                                int off)
 {
     __shared__ int leaf_off[MAX_LEAVES], leaf_len[MAX_LEAVES], leaf_dep[MAX_LEAVES];
     __shared__ double leaf_sum[MAX_LEAVES];
     __shared__ int s_nleaves, st_a[16], st_b[16], st_c[16];
     __shared__ double st_v[16];
     const int lane = threadIdx.x, slot = lane >> 3, k = lane & 7;
-    if (gate && gate[0] >= 0) return;
-    // with n_active the launch has one layer of workgroups and each walks the (few) active candidates:
-    // a layer per possible candidate would be mostly workgroups that start only to return
-    const int cand_end = n_active ? n_active[0] : blockIdx.y + 1;
-    // Workgroups go to the 8 XCDs round-robin.  Eight neighbouring diagonals read the same 64-byte lines of
-    // a row, so each XCD takes whole groups of 8 neighbours (one L2 sees a line once instead of all eight
-    // L2s pulling it across the fabric): within every 64 workgroups the "XCD" and "member" digits swap.
-    const int b = blockIdx.x;
-    const int off = ((((b >> 6) << 3) + (b & 7)) << 3) + ((b >> 3) & 7) + 1;
-    if (off >= n_used) return;
-    for (int cand = n_active ? 0 : blockIdx.y; cand < cand_end; cand++) {
-    const int32_t* __restrict__ p = perms ? perms + (int64_t)cand * (n_head < n_used ? n_head : n_used) : nullptr;
     const int len = n_used - off;
-    auto at = [&](int t) -> int { return t < n_head ? (p ? p[t] : t) : tail_start + (t - n_head); };
-    auto elem = [&](int t) -> double { return M2[(int64_t)at(t) * ld2 + at(t + off)]; };
+    auto elem = [&](int t) -> double { return M2[(int64_t)m.at(t) * ld2 + m.at(t + off)]; };
     double acc = 0.0;                                   // chunk results accumulate left to right from 0.0
     for (int c0 = 0; c0 < len; c0 += 8192) {
         const int clen = len - c0 < 8192 ? len - c0 : 8192;
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(64) void k_p2_diag_sums(const double* __restrict__ 
                 for (int q = 0; q < 16; q++) {
                     const bool ok = l < nl && n >= 8 && q * 8 < lim;
                     const int t = o + q * 8 + k;
-                    const int a = ok ? at(t) : 0, b = ok ? at(t + off) : 0;
+                    const int a = ok ? m.at(t) : 0, b = ok ? m.at(t + off) : 0;
                     idx[q] = (int64_t)a * ld2 + b;
                 }
 #pragma unroll
@@ -161,8 +163,19 @@ __global__ __launch_bounds__(64) void k_p2_diag_sums(const double* __restrict__ 
         __syncthreads();
         if (lane == 0) acc += combine_leaves(nl, leaf_sum, leaf_dep, st_v, st_a);
     }
-    if (lane == 0) T[(int64_t)cand * n_used + off] = acc;
-    }
+    return acc;
+}
+
+// T[cand][off] for off = 1..n_used-1 (T[cand][0] unused).  perms == nullptr: the identity order.
+__global__ __launch_bounds__(64) void k_p2_diag_sums(const double* __restrict__ M2, int64_t ld2,
+                                                     const int32_t* __restrict__ perms, int n_used,
+                                                     double* __restrict__ T)
+{
+    const int cand = blockIdx.y, off = diag_of_block(blockIdx.x);
+    if (off >= n_used) return;
+    const IndexMap m = {perms ? perms + (int64_t)cand * n_used : nullptr, kNoSplice, 0, 0, 0};
+    const double acc = diag_sum_body(M2, ld2, m, n_used, off);
+    if (threadIdx.x == 0) T[(int64_t)cand * n_used + off] = acc;
 }
 
 // The serial parts below are chains of dependent fp64 adds (the reference's order cannot be
@@ -187,22 +200,15 @@ __global__ __launch_bounds__(256) void k_p2_total_exact(const double* __restrict
     total[0] = acc;
 }
 
-// one workgroup per candidate: the running sum of T and the final sum of the quotients are serial
-// (lane 0), the two divisions per offset are done by all lanes in between.
-__global__ __launch_bounds__(256) void k_p2_cost_exact(const double* __restrict__ T, int n_used, double total,
-                                                       double* __restrict__ work, double* __restrict__ scores,
-                                                       const double* __restrict__ total_ptr,
-                                                       const int32_t* __restrict__ gate,
-                                                       const int32_t* __restrict__ n_active)
+// one 256-lane workgroup per candidate: the running sum of T and the final sum of the quotients are serial
+// (lane 0), the two divisions per offset are done by all lanes in between.  tg: the candidate's T row;
+// wg: its n_used doubles of global work space (used when the row does not fit the LDS staging area)
+__device__ __forceinline__ void cost_exact_body(const double* __restrict__ tg, int n_used, double total,
+                                                double* __restrict__ wg, double* __restrict__ score_out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
-    const int cand = blockIdx.x;
-    if (gate && gate[0] >= 0) return;
-    if (n_active && cand >= n_active[0]) return;
-    if (total_ptr) total = total_ptr[0];
-    const double* __restrict__ tg = T + (int64_t)cand * n_used;
     const bool staged = n_used <= SERIAL_LDS_MAX;
-    double* w = staged ? reinterpret_cast<double*>(smem_c) : work + (int64_t)cand * n_used;
+    double* w = staged ? reinterpret_cast<double*>(smem_c) : wg;
     if (staged) {
         for (int i = threadIdx.x; i < n_used; i += 256) w[i] = tg[i];
         __syncthreads();
@@ -221,20 +227,24 @@ __global__ __launch_bounds__(256) void k_p2_cost_exact(const double* __restrict_
         double cost = 0.0;
         if (staged) cost = serial_sum_lds(w, 1, n_used, 0.0);
         else for (int i = 1; i < n_used; i++) cost += w[i];
-        scores[cand] = cost;
+        score_out[0] = cost;
     }
 }
 
-static std::atomic<int> g_lds_total{0}, g_lds_cost{0}, g_lds_score{0};
-static constexpr int kNoTail = 0x7fffffff;
-static int diag_grid(int n_used) { return ((n_used - 1) + 63) & ~63; }     // see the index swap in k_p2_diag_sums
-static const int32_t* const kNoGate = nullptr;
+__global__ __launch_bounds__(256) void k_p2_cost_exact(const double* __restrict__ T, int n_used, double total,
+                                                       double* __restrict__ work, double* __restrict__ scores)
+{
+    const int cand = blockIdx.x;
+    cost_exact_body(T + (int64_t)cand * n_used, n_used, total, work + (int64_t)cand * n_used, scores + cand);
+}
+
+static std::atomic<int> g_lds_total{0}, g_lds_cost{0}, g_lds_score{0}, g_lds_insb_cost{0};
 
 static size_t serial_lds_bytes(int n) { return n <= SERIAL_LDS_MAX ? (((size_t)n * sizeof(double)) + 15) & ~(size_t)15 : 16; }
 
 void launch_p2_total(const double* M2, int64_t ld2, int n, double* T, double* total, hipStream_t s)
 {
-    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n), 1), dim3(64), 0, s, M2, ld2, (const int32_t*)nullptr, n, T, kNoTail, 0, kNoGate, kNoGate);
+    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n), 1), dim3(64), 0, s, M2, ld2, (const int32_t*)nullptr, n, T);
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_total_exact), g_lds_total, 65536);
     hipLaunchKernelGGL(k_p2_total_exact, dim3(1), dim3(256), serial_lds_bytes(n), s, T, n, total);
 }
@@ -242,7 +252,7 @@ void launch_p2_total(const double* M2, int64_t ld2, int n, double* T, double* to
 void launch_p2_total_perm(const double* M2, int64_t ld2, const int32_t* d_perm, int n, double* T, double* total,
                           hipStream_t s)
 {
-    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n), 1), dim3(64), 0, s, M2, ld2, d_perm, n, T, kNoTail, 0, kNoGate, kNoGate);
+    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n), 1), dim3(64), 0, s, M2, ld2, d_perm, n, T);
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_total_exact), g_lds_total, 65536);
     hipLaunchKernelGGL(k_p2_total_exact, dim3(1), dim3(256), serial_lds_bytes(n), s, T, n, total);
 }
@@ -252,27 +262,65 @@ void launch_p2_score_exact(const double* M2, int64_t ld2, const int32_t* perms, 
                            double* T, double* work, double* scores, hipStream_t s)
 {
     if (n_cand <= 0) return;
-    if (n_used > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n_used), n_cand), dim3(64), 0, s, M2, ld2, perms, n_used, T, kNoTail, 0, kNoGate, kNoGate);
+    if (n_used > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n_used), n_cand), dim3(64), 0, s, M2, ld2, perms, n_used, T);
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_cost_exact), g_lds_cost, 65536);
-    hipLaunchKernelGGL(k_p2_cost_exact, dim3(n_cand), dim3(256), serial_lds_bytes(n_used), s, T, n_used, total, work, scores,
-                       (const double*)nullptr, kNoGate, kNoGate);
+    hipLaunchKernelGGL(k_p2_cost_exact, dim3(n_cand), dim3(256), serial_lds_bytes(n_used), s, T, n_used, total, work, scores);
 }
 
-void launch_p2_diag_sums_ex(const double* M2, int64_t ld2, const int32_t* perms, int n_cand, int n_used, int n_head,
-                            int tail_start, const int32_t* gate, const int32_t* n_active, double* T, hipStream_t s)
+// ---- lock-step insertion (k_part2_insert.hip): the same bodies, one layer of workgroups per chromosome ----
+// literal total of "arrangement, then the new scaffold forward" (OG:484-487 -> OG:343): T_total[off]
+__global__ __launch_bounds__(64) void k_insb_diag_total(const InsStep* __restrict__ steps)
 {
-    if (n_cand <= 0 || n_used < 2) return;
-    hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n_used), n_active ? 1 : n_cand), dim3(64), 0, s, M2, ld2, perms, n_used, T,
-                       n_head, tail_start, gate, n_active);
+    const InsStep& d = steps[blockIdx.y];
+    if (!d.active || d.st->fail >= 0) return;
+    const int n_used = d.n_arr + d.L, off = diag_of_block(blockIdx.x);
+    if (off >= n_used) return;
+    const IndexMap m = {d.pos_cur, d.n_arr, 0x3fffffff, d.new_start, 0};
+    const double acc = diag_sum_body(d.M2, d.ld2, m, n_used, off);
+    if (threadIdx.x == 0) d.T_total[off] = acc;
 }
 
-void launch_p2_cost_exact_ex(const double* T, int n_cand, int n_used, const double* total_ptr, const int32_t* gate,
-                             const int32_t* n_active, double* work, double* scores, hipStream_t s)
+// diagonal sums of the short-listed candidates (each workgroup walks the few of its chromosome)
+__global__ __launch_bounds__(64) void k_insb_diag_cand(const InsStep* __restrict__ steps)
 {
-    if (n_cand <= 0) return;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_cost_exact), g_lds_cost, 65536);
-    hipLaunchKernelGGL(k_p2_cost_exact, dim3(n_cand), dim3(256), serial_lds_bytes(n_used), s, T, n_used, 0.0, work, scores,
-                       total_ptr, gate, n_active);
+    const InsStep& d = steps[blockIdx.y];
+    if (!d.active || d.st->fail >= 0) return;
+    const int n_used = d.n_arr + d.L, off = diag_of_block(blockIdx.x);
+    if (off >= n_used) return;
+    const int ns = d.st->n_short;
+    for (int q = 0; q < ns; q++) {
+        const IndexMap m = {d.pos_cur, d.packed_cur[d.S + d.st->gap[q]], d.L, d.new_start, d.st->rev[q]};
+        const double acc = diag_sum_body(d.M2, d.ld2, m, n_used, off);
+        if (threadIdx.x == 0) d.T_cand[(int64_t)q * n_used + off] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_insb_cost(const InsStep* __restrict__ steps)
+{
+    const InsStep& d = steps[blockIdx.y];
+    if (!d.active || d.st->fail >= 0) return;
+    const int cand = blockIdx.x;
+    if (cand >= d.st->n_short) return;
+    const int n_used = d.n_arr + d.L;
+    cost_exact_body(d.T_cand + (int64_t)cand * n_used, n_used, d.st->total, d.work + (int64_t)cand * n_used, d.st->lit + cand);
+}
+
+void launch_insb_diag_total(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s)
+{
+    if (max_n_used < 2) return;
+    hipLaunchKernelGGL(k_insb_diag_total, dim3(diag_grid(max_n_used), n_chrom), dim3(64), 0, s, steps);
+}
+
+void launch_insb_diag_cand(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s)
+{
+    if (max_n_used < 2) return;
+    hipLaunchKernelGGL(k_insb_diag_cand, dim3(diag_grid(max_n_used), n_chrom), dim3(64), 0, s, steps);
+}
+
+void launch_insb_cost(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s)
+{
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_insb_cost), g_lds_insb_cost, 65536);
+    hipLaunchKernelGGL(k_insb_cost, dim3(INS_MAXC, n_chrom), dim3(256), serial_lds_bytes(max_n_used), s, steps);
 }
 
 // One workgroup (4 waves) per candidate.  Wave w takes rows a = w, w+4, ... of the candidate's

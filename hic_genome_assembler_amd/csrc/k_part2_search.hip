@@ -82,39 +82,45 @@ void launch_arr_materialize(const int32_t* packed, int S, const int32_t* scaf_st
 }
 
 // ---- closed-form score of the arrangement itself --------------------------------------------------
-__global__ __launch_bounds__(256) void k_p2_base_partial(const double* __restrict__ M2, int64_t ld2,
-                                                         const int32_t* __restrict__ pos2sel, int n_arr,
-                                                         const double* __restrict__ H, int n_tot,
-                                                         double* __restrict__ partial,
-                                                         const int32_t* __restrict__ gate)
+// slab `blk` of `n_blk`: rows blk*4 + wave, stepping by 4*n_blk (256-lane workgroup); p: the arrangement in LDS
+__device__ __forceinline__ void base_partial_body(const double* __restrict__ M2, int64_t ld2, const int32_t* p, int n_arr,
+                                                  const double* __restrict__ H, int n_tot, int blk, int n_blk,
+                                                  double* __restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int32_t* p = reinterpret_cast<int32_t*>(smem);
     __shared__ double s_w[4];
-    if (gate && gate[0] >= 0) return;
-    for (int q = threadIdx.x; q < n_arr; q += 256) p[q] = pos2sel[q];
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double hn = H[n_tot - 1];
     double acc = 0.0;
-    for (int a = blockIdx.x * 4 + wave; a < n_arr - 1; a += gridDim.x * 4) {
+    for (int a = blk * 4 + wave; a < n_arr - 1; a += n_blk * 4) {
         const double* __restrict__ row = M2 + (int64_t)p[a] * ld2;
 #pragma unroll 4
         for (int b = a + 1 + lane; b < n_arr; b += 64) acc += row[p[b]] * (hn - H[b - a - 1]);
     }
     double sum = block_sum_256(acc, s_w);
-    if (threadIdx.x == 0) partial[blockIdx.x] = sum;
+    if (threadIdx.x == 0) out[0] = sum;
 }
 
-// BASE as partial sums over row slabs: out[0..n_blocks)
-static std::atomic<int> g_lds_base{0}, g_lds_straddle{0}, g_lds_cross{0}, g_lds_wdelta{0};
+__global__ __launch_bounds__(256) void k_p2_base_partial(const double* __restrict__ M2, int64_t ld2,
+                                                         const int32_t* __restrict__ pos2sel, int n_arr,
+                                                         const double* __restrict__ H, int n_tot,
+                                                         double* __restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int32_t* p = reinterpret_cast<int32_t*>(smem);
+    for (int q = threadIdx.x; q < n_arr; q += 256) p[q] = pos2sel[q];
+    __syncthreads();
+    base_partial_body(M2, ld2, p, n_arr, H, n_tot, blockIdx.x, gridDim.x, partial + blockIdx.x);
+}
 
+static std::atomic<int> g_lds_base{0}, g_lds_straddle{0}, g_lds_cross{0}, g_lds_wdelta{0}, g_lds_insb_base{0}, g_lds_insb_fast{0};
+
+// BASE as partial sums over row slabs: out[0..n_blocks)
 void launch_p2_base_partial(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const double* H, int n_tot,
-                            int n_blocks, double* out, hipStream_t s, const int32_t* gate)
+                            int n_blocks, double* out, hipStream_t s)
 {
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_base_partial), g_lds_base, perm_lds_bytes(n_arr));
     hipLaunchKernelGGL(k_p2_base_partial, dim3(n_blocks), dim3(256), perm_lds_bytes(n_arr), s, M2, ld2, pos2sel, n_arr, H,
-                       n_tot, out, gate);
+                       n_tot, out);
 }
 
 // ---- insertion, incremental form ------------------------------------------------------------------
@@ -126,19 +132,12 @@ void launch_p2_base_partial(const double* M2, int64_t ld2, const int32_t* pos2se
 //   CROSS(g, r) = new-scaffold x arrangement pairs + pairs inside the new scaffold
 // STRADDLE(g+1) - STRADDLE(g) only involves the scaffold between the two gaps, so all gaps together
 // cost one pass over the sub-matrix instead of one pass per candidate.
-__global__ __launch_bounds__(1024) void k_p2_insert_straddle(const double* __restrict__ M2, int64_t ld2,
-                                                            const int32_t* __restrict__ pos2sel, int n_arr,
-                                                            const int32_t* __restrict__ arr_pos, int L,
-                                                            const double* __restrict__ H, double* __restrict__ D,
-                                                            const int32_t* __restrict__ gate)
+// Both bodies: 1024-lane workgroup, p = the arrangement in LDS, s_w = 16 doubles of LDS.
+__device__ __forceinline__ void straddle_body(const double* __restrict__ M2, int64_t ld2, const int32_t* p, int n_arr,
+                                              const int32_t* __restrict__ arr_pos, int g, int L,
+                                              const double* __restrict__ H, double* s_w, double* __restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int32_t* p = reinterpret_cast<int32_t*>(smem);
-    __shared__ double s_w[16];
-    if (gate && gate[0] >= 0) return;
-    for (int q = threadIdx.x; q < n_arr; q += 1024) p[q] = pos2sel[q];
-    __syncthreads();
-    const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P0 = arr_pos[g], P1 = arr_pos[g + 1];
     const int len = P1 - P0, n_out = n_arr - len;
     double acc = 0.0;
@@ -156,22 +155,14 @@ __global__ __launch_bounds__(1024) void k_p2_insert_straddle(const double* __res
         }
     }
     double sum = block_sum_1024(acc, s_w);
-    if (threadIdx.x == 0) D[g] = sum;
+    if (threadIdx.x == 0) out[0] = sum;
 }
 
-__global__ __launch_bounds__(1024) void k_p2_insert_cross(const double* __restrict__ M2, int64_t ld2,
-                                                         const int32_t* __restrict__ pos2sel, int n_arr,
-                                                         const int32_t* __restrict__ arr_pos, int new_start, int L,
-                                                         const double* __restrict__ H, double* __restrict__ cross,
-                                                         const int32_t* __restrict__ gate)
+__device__ __forceinline__ void cross_body(const double* __restrict__ M2, int64_t ld2, const int32_t* p, int n_arr,
+                                           const int32_t* __restrict__ arr_pos, int g, int r, int new_start, int L,
+                                           const double* __restrict__ H, double* s_w, double* __restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int32_t* p = reinterpret_cast<int32_t*>(smem);
-    __shared__ double s_w[16];
-    if (gate && gate[0] >= 0) return;
-    for (int q = threadIdx.x; q < n_arr; q += 1024) p[q] = pos2sel[q];
-    __syncthreads();
-    const int g = blockIdx.x >> 1, r = blockIdx.x & 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P = arr_pos[g];
     const double hn = H[n_arr + L - 1];
     double acc = 0.0;
@@ -189,22 +180,90 @@ __global__ __launch_bounds__(1024) void k_p2_insert_cross(const double* __restri
         }
     }
     double sum = block_sum_1024(acc, s_w);
-    if (threadIdx.x == 0) cross[blockIdx.x] = sum;
+    if (threadIdx.x == 0) out[0] = sum;
+}
+
+__global__ __launch_bounds__(1024) void k_p2_insert_straddle(const double* __restrict__ M2, int64_t ld2,
+                                                            const int32_t* __restrict__ pos2sel, int n_arr,
+                                                            const int32_t* __restrict__ arr_pos, int L,
+                                                            const double* __restrict__ H, double* __restrict__ D)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int32_t* p = reinterpret_cast<int32_t*>(smem);
+    __shared__ double s_w[16];
+    for (int q = threadIdx.x; q < n_arr; q += 1024) p[q] = pos2sel[q];
+    __syncthreads();
+    straddle_body(M2, ld2, p, n_arr, arr_pos, blockIdx.x, L, H, s_w, D + blockIdx.x);
+}
+
+__global__ __launch_bounds__(1024) void k_p2_insert_cross(const double* __restrict__ M2, int64_t ld2,
+                                                         const int32_t* __restrict__ pos2sel, int n_arr,
+                                                         const int32_t* __restrict__ arr_pos, int new_start, int L,
+                                                         const double* __restrict__ H, double* __restrict__ cross)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int32_t* p = reinterpret_cast<int32_t*>(smem);
+    __shared__ double s_w[16];
+    for (int q = threadIdx.x; q < n_arr; q += 1024) p[q] = pos2sel[q];
+    __syncthreads();
+    cross_body(M2, ld2, p, n_arr, arr_pos, blockIdx.x >> 1, blockIdx.x & 1, new_start, L, H, s_w, cross + blockIdx.x);
 }
 
 void launch_p2_insert_delta(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const int32_t* arr_pos,
-                            int S, int new_start, int L, const double* H, int n_base_blocks, double* out, hipStream_t s,
-                            const int32_t* gate)
+                            int S, int new_start, int L, const double* H, int n_base_blocks, double* out, hipStream_t s)
 {
     // out: [n_base_blocks partial sums of BASE][S straddle increments][2(S+1) cross terms]
     const size_t lds = perm_lds_bytes(n_arr);
-    launch_p2_base_partial(M2, ld2, pos2sel, n_arr, H, n_arr + L, n_base_blocks, out, s, gate);
+    launch_p2_base_partial(M2, ld2, pos2sel, n_arr, H, n_arr + L, n_base_blocks, out, s);
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_insert_straddle), g_lds_straddle, lds);
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_insert_cross), g_lds_cross, lds);
     hipLaunchKernelGGL(k_p2_insert_straddle, dim3(S), dim3(1024), lds, s, M2, ld2, pos2sel, n_arr, arr_pos, L, H,
-                       out + n_base_blocks, gate);
+                       out + n_base_blocks);
     hipLaunchKernelGGL(k_p2_insert_cross, dim3(2 * (S + 1)), dim3(1024), lds, s, M2, ld2, pos2sel, n_arr, arr_pos, new_start,
-                       L, H, out + n_base_blocks + S, gate);
+                       L, H, out + n_base_blocks + S);
+}
+
+// ---- lock-step insertion (k_part2_insert.hip): one layer of workgroups per chromosome --------------
+// partial layout per chromosome: [n_base_blocks BASE slabs][S STRADDLE increments][2(S+1) CROSS terms]
+__global__ __launch_bounds__(256) void k_insb_base(const InsStep* __restrict__ steps, int n_base_blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int32_t* p = reinterpret_cast<int32_t*>(smem);
+    const InsStep& d = steps[blockIdx.y];
+    if (!d.active || d.st->fail >= 0) return;
+    for (int q = threadIdx.x; q < d.n_arr; q += 256) p[q] = d.pos_cur[q];
+    __syncthreads();
+    base_partial_body(d.M2, d.ld2, p, d.n_arr, d.H, d.n_arr + d.L, blockIdx.x, n_base_blocks, d.partial + blockIdx.x);
+}
+
+// workgroups [0, S): STRADDLE increments; [S, S + 2(S+1)): CROSS terms
+__global__ __launch_bounds__(1024) void k_insb_fast(const InsStep* __restrict__ steps, int n_base_blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int32_t* p = reinterpret_cast<int32_t*>(smem);
+    __shared__ double s_w[16];
+    const InsStep& d = steps[blockIdx.y];
+    if (!d.active || d.st->fail >= 0) return;
+    const int b = blockIdx.x, S = d.S;
+    if (b >= S + 2 * (S + 1)) return;
+    for (int q = threadIdx.x; q < d.n_arr; q += 1024) p[q] = d.pos_cur[q];
+    __syncthreads();
+    const int32_t* __restrict__ arr_pos = d.packed_cur + S;
+    if (b < S) straddle_body(d.M2, d.ld2, p, d.n_arr, arr_pos, b, d.L, d.H, s_w, d.partial + n_base_blocks + b);
+    else {
+        const int c = b - S;
+        cross_body(d.M2, d.ld2, p, d.n_arr, arr_pos, c >> 1, c & 1, d.new_start, d.L, d.H, s_w,
+                   d.partial + n_base_blocks + S + c);
+    }
+}
+
+void launch_insb_fast(const InsStep* steps, int n_chrom, int max_S, int max_n_arr, int n_base_blocks, hipStream_t s)
+{
+    const size_t lds = perm_lds_bytes(max_n_arr);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_insb_base), g_lds_insb_base, lds);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_insb_fast), g_lds_insb_fast, lds);
+    hipLaunchKernelGGL(k_insb_base, dim3(n_base_blocks, n_chrom), dim3(256), lds, s, steps, n_base_blocks);
+    hipLaunchKernelGGL(k_insb_fast, dim3(max_S + 2 * (max_S + 1), n_chrom), dim3(1024), lds, s, steps, n_base_blocks);
 }
 
 // ---- window: G table ----------------------------------------------------------------------------

@@ -27,11 +27,12 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import _lib
-from .hostio import Bin, initiateLoci, read_contact_matrix  # noqa: F401
+from .hostio import Bin, initiateLoci, paused_gc, read_contact_matrix  # noqa: F401
 
 SCORE_HOOK = None      # tests: called with the fast scores of every step, in enumeration order
 _PROFILE = bool(os.environ.get("HICMI_PART2_PROFILE"))   # per-chromosome wall clock on stderr
-WORKERS = int(os.environ.get("HICMI_PART2_WORKERS", "8"))   # chromosomes ordered concurrently (1 = sequential)
+WORKERS = int(os.environ.get("HICMI_PART2_WORKERS", "8"))
+LOCKSTEP = os.environ.get("HICMI_PART2_LOCKSTEP", "1") != "0"   # all chromosomes' insertion loops in one queue of launches   # chromosomes ordered concurrently (1 = sequential)
 NEAR_TOP = 1e-9        # relative band around a step's best fast score that is re-scored literally
 
 
@@ -496,19 +497,33 @@ def checkAllScores(adjMat: SubMatrix, orderDict, orderedScaffs, scaffToCheck):
     return orderedScaffs, bestCost
 
 
-def orderRemainderScaffolds(orderedScaffolds, scaffoldList, orderDict, matrix: GenomeMatrix, binList):
-    """OG:475-493 (a do-while: with nothing left to add, the last ordered scaffold is re-inserted)."""
+def _insertion_job(orderedScaffolds, scaffoldList, matrix: GenomeMatrix):
+    """(ids, rev, new_ids) for hicmi_p2_insert_all, or None when the whole-loop call does not apply (test
+    doubles, score hooks, nothing left to add, a scaffold that was flipped before)."""
     layout = matrix.chrom
     if (layout is not None and _fused(matrix.ctx) and len(scaffoldList) > 0 and len(orderedScaffolds) > 0
             and layout.covers(orderedScaffolds) and layout.covers(scaffoldList)
             and all(s.orientation == "+" for s in scaffoldList)):
         ids, rev = layout.describe(orderedScaffolds)
-        new_ids = [layout.sid[s.name] for s in scaffoldList]
-        by_name = {s.name: s for s in orderedScaffolds + scaffoldList}
-        ids, rev, bestCost = matrix.ctx.p2_insert_all(ids, rev, new_ids)
-        del scaffoldList[:]
-        orderedScaffolds, _nodes = reorderScaffList([layout.names[i] for i in ids], ["-" if r else "+" for r in rev], by_name)
-        return orderedScaffolds, bestCost
+        return ids, rev, [layout.sid[s.name] for s in scaffoldList]
+    return None
+
+
+def _insertion_result(ids, rev, orderedScaffolds, scaffoldList, matrix: GenomeMatrix):
+    """Scaffold objects in the order / orientation hicmi_p2_insert_all returned; empties scaffoldList."""
+    layout = matrix.chrom
+    by_name = {s.name: s for s in orderedScaffolds + scaffoldList}
+    del scaffoldList[:]
+    ordered, _nodes = reorderScaffList([layout.names[i] for i in ids], ["-" if r else "+" for r in rev], by_name)
+    return ordered
+
+
+def orderRemainderScaffolds(orderedScaffolds, scaffoldList, orderDict, matrix: GenomeMatrix, binList):
+    """OG:475-493 (a do-while: with nothing left to add, the last ordered scaffold is re-inserted)."""
+    job = _insertion_job(orderedScaffolds, scaffoldList, matrix)
+    if job is not None:
+        ids, rev, bestCost = matrix.ctx.p2_insert_all(*job)
+        return _insertion_result(ids, rev, orderedScaffolds, scaffoldList, matrix), bestCost
     while True:
         orderedScaffolds, scaffoldList = pullScaffolds(orderedScaffolds, scaffoldList, 1)
         adjMat, orderDict = giveNewAdjMat(matrix, orderedScaffolds, binList)
@@ -581,8 +596,9 @@ def scanOrdering(orderedScaffolds, scaffoldDict, orderDict, matrix: GenomeMatrix
     return orderedScaffolds, bestCost
 
 
-def orderChromosome(chromGroup, matrix: GenomeMatrix, binList, nScaffolds=6, scanScaffolds=5):
-    """OG:551-586."""
+def _startChromosome(chromGroup, matrix: GenomeMatrix, binList, nScaffolds=6, scanScaffolds=5):
+    """OG:551-576: the selection, the brute-force order of the largest scaffolds; returns the state the
+    insertion and scan phases continue from."""
     if nScaffolds >= 9:
         print("Number of initial scaffolds to order by brute force method is set too high... setting it to 8")
         nScaffolds = 8
@@ -594,16 +610,29 @@ def orderChromosome(chromGroup, matrix: GenomeMatrix, binList, nScaffolds=6, sca
     adjMat, orderDict = giveNewAdjMat(matrix, orderedScaffolds, binList)
     bfOrder, bfOrient, _bfScore = bruteForceBestScore(orderedScaffolds, scaffoldDict, adjMat, orderDict)
     orderedScaffolds, _nodes = reorderScaffList(bfOrder, bfOrient, scaffoldDict)
-    orderedScaffolds, bestCost = orderRemainderScaffolds(orderedScaffolds, scaffoldList, orderDict, matrix, binList)
+    return {"ordered": orderedScaffolds, "rest": scaffoldList, "dict": scaffoldDict, "orderDict": orderDict,
+            "nScaffolds": nScaffolds, "scanScaffolds": scanScaffolds}
+
+
+def _finishChromosome(state, orderedScaffolds, bestCost, matrix: GenomeMatrix, binList):
+    """OG:578-586: the sliding-window rounds and the final listing."""
     print("BestCost at the end of first two steps " + str(bestCost))
-    if len(orderedScaffolds) > nScaffolds:
-        orderedScaffolds, bestCost = scanOrdering(orderedScaffolds, scaffoldDict, orderDict, matrix, binList,
-                                                  bestCost, scanScaffolds=scanScaffolds)
+    if len(orderedScaffolds) > state["nScaffolds"]:
+        orderedScaffolds, bestCost = scanOrdering(orderedScaffolds, state["dict"], state["orderDict"], matrix, binList,
+                                                  bestCost, scanScaffolds=state["scanScaffolds"])
     print("Final ordering...")
     for s in orderedScaffolds:
         print(s.name, s.orientation)
     orderChromosome.last_cost = bestCost
     return orderedScaffolds
+
+
+def orderChromosome(chromGroup, matrix: GenomeMatrix, binList, nScaffolds=6, scanScaffolds=5):
+    """OG:551-586."""
+    state = _startChromosome(chromGroup, matrix, binList, nScaffolds, scanScaffolds)
+    orderedScaffolds, bestCost = orderRemainderScaffolds(state["ordered"], state["rest"], state["orderDict"], matrix,
+                                                         binList)
+    return _finishChromosome(state, orderedScaffolds, bestCost, matrix, binList)
 
 
 def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds=6, scanScaffolds=5, plotChrom=True,
@@ -631,6 +660,47 @@ def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds
 
     if n_workers == 1 or not hasattr(matrix.ctx, "workers"):
         fullGenomeOrder = [one(i, matrix) for i in range(len(chromList))]
+    elif LOCKSTEP and hasattr(matrix.ctx, "p2_insert_all_multi"):
+        # Three phases over ALL chromosomes, one context each: (1) selection + brute force on worker threads,
+        # (2) every chromosome's insertion loop in lock step, decided on the device - one queue of launches
+        # serving all of them (hicmi_p2_insert_all_multi), (3) the sliding-window rounds on worker threads.
+        lanes = [matrix] + [GenomeMatrix(c) for c in matrix.ctx.workers(len(chromList) - 1)]
+        for m in lanes[1:]:
+            m._bin_index, m._bin_index_src = matrix._bin_index, matrix._bin_index_src
+        todo = sorted(range(len(chromList)), key=lambda i: -len(chromList[i]))     # largest first
+        marks = [time.perf_counter()]
+
+        def start(i):
+            print("#####################\n#####################")
+            print("Working on Chr_" + str(i + 1) + "...")
+            return i, _startChromosome(chromList[i], lanes[i], binList, nScaffolds, scanScaffolds)
+        with ThreadPoolExecutor(max_workers=n_workers) as pool:
+            states = dict(pool.map(start, todo))
+            marks.append(time.perf_counter())
+            jobs, job_of, inserted = [], [], {}
+            for i in todo:
+                job = _insertion_job(states[i]["ordered"], states[i]["rest"], lanes[i])
+                if job is not None:
+                    jobs.append((lanes[i].ctx,) + job)
+                    job_of.append(i)
+            for i, (ids, rev, best) in zip(job_of, matrix.ctx.p2_insert_all_multi(jobs)):
+                st = states[i]
+                inserted[i] = (_insertion_result(ids, rev, st["ordered"], st["rest"], lanes[i]), best)
+            marks.append(time.perf_counter())
+
+            def finish(i):
+                st = states[i]
+                if i not in inserted:                                           # e.g. nothing left to add (OG:475-493)
+                    inserted[i] = orderRemainderScaffolds(st["ordered"], st["rest"], st["orderDict"], lanes[i], binList)
+                ordered, best = inserted[i]
+                return i, _finishChromosome(st, ordered, best, lanes[i], binList)
+            done = dict(pool.map(finish, todo))
+        marks.append(time.perf_counter())
+        if _PROFILE:
+            sys.stderr.write("[hicmi] part2 lock step: start %.1f ms, insertion %.1f ms (%d chromosomes), scan %.1f ms\n"
+                             % ((marks[1] - marks[0]) * 1e3, (marks[2] - marks[1]) * 1e3, len(jobs),
+                                (marks[3] - marks[2]) * 1e3))
+        fullGenomeOrder = [done[i] for i in range(len(chromList))]
     else:
         lanes = [matrix] + [GenomeMatrix(c) for c in matrix.ctx.workers(n_workers - 1)]
         for m in lanes[1:]:
@@ -711,9 +781,10 @@ def runResident(adjMat: GenomeMatrix, binList, chromosomeGroupFile, chromosomeOr
     gives the bin of every row of the device matrix; bins that Part 1 did not assign to a group are
     simply never selected, which is what the reference's re-load restricted to grouped bins
     (OG:688-690) amounts to."""
-    chromosomeList = readChromsFromFile(chromosomeGroupFile)
-    orderedChromosomes = orderGenome(adjMat, chromosomeList, binList, resolution, nScaffolds=nScaffolds,
-                                     scanScaffolds=scanScaffolds, plotChrom=True, showPlot=False)
-    writeScaffoldOrderingsToFile(orderedChromosomes, chromosomeOrderFile)
-    writeBinIDsOrderingToFile([s for group in orderedChromosomes for s in group], plotOrderFile)
+    with paused_gc():
+        chromosomeList = readChromsFromFile(chromosomeGroupFile)
+        orderedChromosomes = orderGenome(adjMat, chromosomeList, binList, resolution, nScaffolds=nScaffolds,
+                                         scanScaffolds=scanScaffolds, plotChrom=True, showPlot=False)
+        writeScaffoldOrderingsToFile(orderedChromosomes, chromosomeOrderFile)
+        writeBinIDsOrderingToFile([s for group in orderedChromosomes for s in group], plotOrderFile)
     return orderedChromosomes

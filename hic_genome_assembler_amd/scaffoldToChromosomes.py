@@ -28,7 +28,7 @@ import time
 import numpy as np
 
 from . import _lib
-from .hostio import Bin, initiateLoci, read_contact_matrix  # noqa: F401  (re-exported reference names)
+from .hostio import Bin, initiateLoci, paused_gc, read_contact_matrix  # noqa: F401  (re-exported reference names)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -439,28 +439,29 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
     """S2C:1117-1167 on a contact map that is already resident in HBM (what bench.py times): every
     stage after the text loaders, including the small intermediate files the reference round-trips
     through.  Returns the filtered cut indices; ``binList`` is left in .bed order for the caller."""
-    t0 = time.time()
-    adjMat, binList = removeRows(adjMat, binList, zeroRows=True, biasVals=False)
-    adjMat.kept_bins = list(binList)                  # rows of the device matrix, in .bed order
-    adjMat = convertMatrix(adjMat, binList, distance=True, similarity=False)
-    dendroLabels = [b.chrom + '_' + str(b.ID) for b in binList]
-    dendrogram = averageClusterNodes(adjMat, dendroLabels, noPlot=True)
-    dendrogramLeafOrder_toFile(dendrogram, dendrogramOrderFile)
-    # the reference parses the file back (readDengrogramLeavesFromFile); the leaves are the same integers
-    adjMat, binList = reorderMatrix(adjMat, binList, dendrogram['leaves'])
-    print("Total run-time to cluster = " + str(time.time() - t0))
-    t0 = time.time()
-    adjMat = convertMatrix(adjMat, binList, distance=False, similarity=True)
-    argsorted_adjMat = rankOrderMatrix(adjMat)
-    initial_cut_inds = pre_process_all_matrix_breakpoints(argsorted_adjMat, min_size=minSize,
-                                                          min_frac=modularity, psig=psig)
-    cutIndices = filter_noisy_breakpoints(argsorted_adjMat, initial_cut_inds, psig=psig)
-    binGroups = writeBinGroupingsToFile(cutIndices, binList, binGroupFile)
-    print("Total run-time to identify chromosome boundaries = " + str(time.time() - t0))
-    t0 = time.time()
-    fastaSizeDict = readSizeFileToDict(hicProScaffSizeFile)
-    print(str(len(binGroups)) + " chromosomes read in from file")      # == readBinGroupingsFromFile(binGroupFile)
-    chrGroups = assessChromosomeClustering(binGroups, assessmentFile)
-    writeChromosomeGroupingsToFile(chrGroups, fastaSizeDict, chromosomeGroupFile)
-    print("Total run-time to assign scaffolds to chromosomes = " + str(time.time() - t0))
+    with paused_gc():
+        t0 = time.time()
+        adjMat, binList = removeRows(adjMat, binList, zeroRows=True, biasVals=False)
+        adjMat.kept_bins = list(binList)                  # rows of the device matrix, in .bed order
+        adjMat = convertMatrix(adjMat, binList, distance=True, similarity=False)
+        dendroLabels = [b.chrom + '_' + str(b.ID) for b in binList]
+        dendrogram = averageClusterNodes(adjMat, dendroLabels, noPlot=True)
+        dendrogramLeafOrder_toFile(dendrogram, dendrogramOrderFile)
+        # the reference parses the file back (readDengrogramLeavesFromFile); the leaves are the same integers
+        adjMat, binList = reorderMatrix(adjMat, binList, dendrogram['leaves'])
+        print("Total run-time to cluster = " + str(time.time() - t0))
+        t0 = time.time()
+        adjMat = convertMatrix(adjMat, binList, distance=False, similarity=True)
+        argsorted_adjMat = rankOrderMatrix(adjMat)
+        initial_cut_inds = pre_process_all_matrix_breakpoints(argsorted_adjMat, min_size=minSize,
+                                                              min_frac=modularity, psig=psig)
+        cutIndices = filter_noisy_breakpoints(argsorted_adjMat, initial_cut_inds, psig=psig)
+        binGroups = writeBinGroupingsToFile(cutIndices, binList, binGroupFile)
+        print("Total run-time to identify chromosome boundaries = " + str(time.time() - t0))
+        t0 = time.time()
+        fastaSizeDict = readSizeFileToDict(hicProScaffSizeFile)
+        print(str(len(binGroups)) + " chromosomes read in from file")      # == readBinGroupingsFromFile(binGroupFile)
+        chrGroups = assessChromosomeClustering(binGroups, assessmentFile)
+        writeChromosomeGroupingsToFile(chrGroups, fastaSizeDict, chromosomeGroupFile)
+        print("Total run-time to assign scaffolds to chromosomes = " + str(time.time() - t0))
     return cutIndices

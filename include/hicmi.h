@@ -208,6 +208,13 @@ int hicmi_p2_insert_all(hicmi_ctx *ctx, int32_t *ids, uint8_t *rev, int64_t S0, 
                         double *best_out);
 int hicmi_p2_scan_pass(hicmi_ctx *ctx, int32_t *ids, uint8_t *rev, int64_t S, int64_t k, double total, double *best_io,
                        double *cur_fast_io, int32_t *improved_out);
+/* hicmi_p2_insert_all for n_jobs chromosomes at once (the loop over chromosomes of OG:608-612 turned
+ * inside out): job j uses context ctxs[j] - its own selection and layout, all contexts on one device - and
+ * the arrays ids[j] / rev[j] / new_ids[j] with S0[j] / n_new[j] entries as above.  The chromosomes advance
+ * in lock step, every step of all of them decided on the device; best_out[j] as for hicmi_p2_insert_all.
+ * Must not run concurrently with other calls on any of the contexts. */
+int hicmi_p2_insert_all_multi(int64_t n_jobs, hicmi_ctx *const *ctxs, int32_t *const *ids, uint8_t *const *rev,
+                              const int64_t *S0, const int32_t *const *new_ids, const int64_t *n_new, double *best_out);
 
 /* ---- timing ----------------------------------------------------------------------------------
  * Accumulated device time (HIP events on the context stream) per kernel family since the last
