@@ -11,6 +11,9 @@ from __future__ import annotations
 
 import contextlib
 import gc
+import hashlib
+import json
+import os
 
 import numpy as np
 
@@ -64,6 +67,51 @@ def initiateLoci(bedFile, biasFile, binID_dict=False):
             bins.append(Bin(bid, cols[0], int(cols[1]), int(cols[2]), value, 0.))
     print("Genomic loci found" + "\t" + str(len(bins)))
     return bins
+
+
+def _cache_paths(matrixFile, cache):
+    """Where the binary copy of a parsed matrix lives: next to the text file (cache=True / "1") or in
+    the directory given."""
+    if cache in (True, "1", "true", "yes"):
+        base = matrixFile
+    else:
+        base = os.path.join(str(cache), os.path.basename(matrixFile))
+    return base + ".hicmi.npy", base + ".hicmi.json"
+
+
+def _cache_key(matrixFile, ids):
+    st = os.stat(matrixFile)
+    return {"source_bytes": int(st.st_size), "source_mtime_ns": int(st.st_mtime_ns), "bins": int(len(ids)),
+            "bin_ids_sha1": hashlib.sha1(np.ascontiguousarray(ids, dtype=np.int64).tobytes()).hexdigest(),
+            "format": 1}
+
+
+def read_contact_matrix_cached(matrixFile, binList, cache, engine: str = "native") -> np.ndarray:
+    """read_contact_matrix with a binary cache: the dense fp64 array is stored as
+    .npy beside a small JSON key (size and mtime of the text file, number and SHA-1 of the bin IDs in
+    order); a matching key means the text is not parsed again and the array is memory-mapped read-only.
+    A stale or unreadable cache is ignored and rewritten."""
+    ids = np.fromiter((b.ID for b in binList), dtype=np.int64, count=len(binList))
+    npy, key_file = _cache_paths(matrixFile, cache)
+    key = _cache_key(matrixFile, ids)
+    try:
+        with open(key_file) as fh:
+            if json.load(fh) == key:
+                mat = np.load(npy, mmap_mode="r", allow_pickle=False)
+                if mat.shape == (len(ids), len(ids)) and mat.dtype == np.float64:
+                    print("Adjacency matrix read from binary cache " + npy)
+                    return mat
+    except (OSError, ValueError):
+        pass
+    mat = read_contact_matrix(matrixFile, binList, engine=engine)
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(npy)), exist_ok=True)
+        np.save(npy, mat, allow_pickle=False)
+        with open(key_file, "w") as fh:
+            json.dump(key, fh)
+    except OSError as exc:                                  # a read-only input directory must not fail the run
+        print("WARNING - could not write the matrix cache: " + str(exc))
+    return mat
 
 
 def read_contact_matrix(matrixFile, binList, chunk_lines: int = 4_000_000, engine: str = "native") -> np.ndarray:

@@ -27,7 +27,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import _lib
-from .hostio import Bin, initiateLoci, paused_gc, read_contact_matrix  # noqa: F401
+from .hostio import Bin, initiateLoci, paused_gc, read_contact_matrix, read_contact_matrix_cached  # noqa: F401
 
 SCORE_HOOK = None      # tests: called with the fast scores of every step, in enumeration order
 _PROFILE = bool(os.environ.get("HICMI_PART2_PROFILE"))   # per-chromosome wall clock on stderr
@@ -182,7 +182,8 @@ class SubMatrix:
 
 def buildAdjacencyMatrix(matrixFile, binList, binID_dict=False, device=0, ctx=None):
     """OG:65-93."""
-    host = read_contact_matrix(matrixFile, binList)
+    cache = os.environ.get("HICMI_MATRIX_CACHE")           # "1": beside the text file; or a directory (hostio.py)
+    host = read_contact_matrix_cached(matrixFile, binList, cache) if cache else read_contact_matrix(matrixFile, binList)
     ctx = ctx or _lib.Context(device)
     ctx.set_contacts(host)
     print("Rows in adjacency matrix " + str(len(binList)))

@@ -23,12 +23,13 @@ Not implemented: the HMM boundary finder, th
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
 
 from . import _lib
-from .hostio import Bin, initiateLoci, paused_gc, read_contact_matrix  # noqa: F401  (re-exported reference names)
+from .hostio import Bin, initiateLoci, paused_gc, read_contact_matrix, read_contact_matrix_cached  # noqa: F401  (re-exported reference names)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -66,7 +67,8 @@ class RankMatrix:
 
 def buildAdjacencyMatrix(matrixFile, binList, binID_dict=False, device=0, ctx=None):
     """S2C:70-98: dense matrix from HiC-Pro triplets, uploaded once to HBM."""
-    host = read_contact_matrix(matrixFile, binList)
+    cache = os.environ.get("HICMI_MATRIX_CACHE")           # "1": beside the text file; or a directory (hostio.py)
+    host = read_contact_matrix_cached(matrixFile, binList, cache) if cache else read_contact_matrix(matrixFile, binList)
     ctx = ctx or _lib.Context(device)
     ctx.set_contacts(host)
     print("Rows in adjacency matrix " + str(len(binList)))

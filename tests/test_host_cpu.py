@@ -201,3 +201,32 @@ def test_intermediate_files_round_trip(tmp_path):
     report = open(tmp_path / "a.txt").read()
     assert "scaf1\t2\t7\t28.57%" in report and "scaf1\t5\t7\t71.43%" in report
     assert "Falsely clustered nodes 4" in report
+
+
+def test_matrix_binary_cache(tmp_path):
+    """the parsed matrix is cached as .npy under a key of the text file's size/mtime and the
+    bin IDs; a matching key skips the parse, a changed text file or bin list invalidates it."""
+    from hic_genome_assembler_amd import hostio, synth
+    lay = synth.make_layout(120, seed=3)
+    c = synth.dense_contacts(lay, seed=3, sinkhorn_iters=4)
+    files = synth.write_hicpro(str(tmp_path), lay, c, "m")
+    paths = {"matrix": files["hicProMatrixFile"]}
+    bins = hostio.initiateLoci(files["hicProBedFile"], files["hicProBiasFile"])
+    cache_dir = tmp_path / "cache"
+    first = np.array(hostio.read_contact_matrix_cached(paths["matrix"], bins, str(cache_dir)))
+    assert np.array_equal(first, hostio.read_contact_matrix(paths["matrix"], bins))
+    npy = cache_dir / (os.path.basename(paths["matrix"]) + ".hicmi.npy")
+    assert npy.exists()
+    # served from the cache: poison the cached array and see the poison come back
+    poisoned = first.copy(); poisoned[0, 0] = -123.0
+    np.save(str(npy), poisoned)
+    again = hostio.read_contact_matrix_cached(paths["matrix"], bins, str(cache_dir))
+    assert again[0, 0] == -123.0 and not again.flags.writeable
+    # a different bin list (one bin dropped) must not be served from it
+    fewer = hostio.read_contact_matrix_cached(paths["matrix"], bins[1:], str(cache_dir))
+    assert fewer.shape == (len(bins) - 1, len(bins) - 1) and np.array_equal(np.asarray(fewer), first[1:, 1:])
+    # ... and neither must a modified text file
+    with open(paths["matrix"], "a") as fh:
+        fh.write("%d\t%d\t7.5\n" % (bins[1].ID, bins[2].ID))
+    fresh = hostio.read_contact_matrix_cached(paths["matrix"], bins[1:], str(cache_dir))
+    assert fresh[0, 1] == 7.5 and fresh[1, 0] == 7.5
