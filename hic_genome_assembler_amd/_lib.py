@@ -62,6 +62,8 @@ SIGNATURES = {
                                                  ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_int32),
                                                  ctypes.POINTER(c_dbl)]),
     "hicmi_p2_insert_all": (ctypes.c_int, [_vp, _vp, _vp, c_i64, _vp, c_i64, ctypes.POINTER(c_dbl)]),
+    "hicmi_plot_percentiles": (ctypes.c_int, [_vp, ctypes.c_int, _vp, c_i64, _vp, c_i64, _vp]),
+    "hicmi_plot_downsample": (ctypes.c_int, [_vp, ctypes.c_int, _vp, c_i64, c_i64, _vp]),
     "hicmi_p2_insert_all_multi": (ctypes.c_int, [c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hicmi_p2_scan_pass": (ctypes.c_int, [_vp, _vp, _vp, c_i64, c_i64, c_dbl, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl),
                                           ctypes.POINTER(ctypes.c_int32)]),
@@ -386,6 +388,30 @@ class Context:
                                             ctypes.byref(cf), ctypes.byref(imp)))
         self._arr_sig = None
         return a, b, bst.value, cf.value, bool(imp.value)
+
+    # ---- plot support
+    def plot_percentiles(self, kind, order, q):
+        """numpy.percentile (linear) of the cells of the (transformed) matrix restricted to ``order``."""
+        qa = np.ascontiguousarray(q, dtype=np.float64)
+        out = np.empty(len(qa), np.float64)
+        if order is None:
+            n_sel, optr, keep = self.n, None, None
+        else:
+            keep = np.ascontiguousarray(order, dtype=np.int32)
+            n_sel, optr = len(keep), _ptr(keep)
+        _check(self._lib.hicmi_plot_percentiles(self._h, int(kind), optr, n_sel, _ptr(qa), len(qa), _ptr(out)))
+        return out
+
+    def plot_downsample(self, kind, order, px):
+        """px x px block means of the (transformed) matrix restricted / permuted by ``order``."""
+        if order is None:
+            n_sel, optr, keep = self.n, None, None
+        else:
+            keep = np.ascontiguousarray(order, dtype=np.int32)
+            n_sel, optr = len(keep), _ptr(keep)
+        out = np.empty((int(px), int(px)), np.float64)
+        _check(self._lib.hicmi_plot_downsample(self._h, int(kind), optr, n_sel, int(px), _ptr(out)))
+        return out
 
     # ---- misc
     def synchronize(self):

@@ -41,10 +41,10 @@ namespace hicmi { int set_error(int code, const char* msg) { return fail(code, "
     } while (0)
 
 enum Family { F_ROW_SUMS, F_BUILD_W, F_NNCHAIN, F_SORT, F_RANK_INVERT, F_CUT_COUNT, F_HYPER_FLAGS, F_P2_SELECT,
-              F_P2_TOTAL, F_P2_SCORE, F_P2_EXACT, F_P2_INSERT, F_P2_WINDOW_G, F_P2_WINDOW_DELTA, F_COUNT };
+              F_P2_TOTAL, F_P2_SCORE, F_P2_EXACT, F_P2_INSERT, F_P2_WINDOW_G, F_P2_WINDOW_DELTA, F_PLOT, F_COUNT };
 static const char* kFamilyNames[F_COUNT] = {"row_sums", "build_w", "nnchain", "sort_rows", "rank_invert",
                                             "cut_count", "hyper_flags", "p2_select", "p2_total", "p2_score",
-                                            "p2_score_exact", "p2_score_insert", "p2_window_G", "p2_window_delta"};
+                                            "p2_score_exact", "p2_score_insert", "p2_window_G", "p2_window_delta", "plot"};
 
 constexpr int kBaseSlabs = 256;                        // partial sums of the closed-form BASE term (one slab per workgroup)
 
@@ -104,6 +104,10 @@ struct hicmi_ctx {
     double* d_ins_partial = nullptr; int64_t ins_partial_cap = 0;
     unsigned char* d_ins_blob = nullptr; int64_t ins_blob_cap = 0;   // per job: [InsState][InsLog x steps]
     InsStep* d_ins_steps = nullptr; int64_t ins_steps_cap = 0;       // [step][job] records of a lock-step queue
+    // plot support
+    int32_t* d_plot_order = nullptr; int64_t plot_order_cap = 0;
+    unsigned char* d_plot_work = nullptr; int64_t plot_work_cap = 0;
+    double* d_plot_img = nullptr; int64_t plot_img_cap = 0;
     // pinned staging: pageable hipMemcpyAsync takes a slow, serialising path in the runtime, which hurts when
     // several contexts are driven from different host threads
     char* pin_up = nullptr; size_t pin_up_cap = 0, pin_up_off = 0;
@@ -294,6 +298,7 @@ int hicmi_destroy(hicmi_ctx* c)
     free_dev(c->d_G); free_dev(c->d_delta); free_dev(c->d_wb);
     free_dev(c->d_arr_packed2); free_dev(c->d_pos2sel2); free_dev(c->d_ins_T); free_dev(c->d_ins_partial);
     free_dev(c->d_ins_blob); free_dev(c->d_ins_steps);
+    free_dev(c->d_plot_order); free_dev(c->d_plot_work); free_dev(c->d_plot_img);
     if (c->pin_up) (void)hipHostFree(c->pin_up);
     if (c->pin_down) (void)hipHostFree(c->pin_down);
     for (auto& r : c->regions) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -1474,6 +1479,96 @@ int hicmi_p2_scan_pass(hicmi_ctx* c, int32_t* ids, uint8_t* rev, int64_t S, int6
         if (!applied) { first += count; batch = std::min<int64_t>(batch * 2, 32); }
     }
     return HICMI_OK;
+}
+
+// ---- plot support (plotContactMaps.py:15-91) --------------------------------------------------------
+namespace {
+int plot_prepare(hicmi_ctx* c, int kind, const int32_t* order, int64_t n_sel, int32_t** d_order_out)
+{
+    if (!c->dC) return fail(HICMI_EINVAL, "no contact matrix set");
+    if (kind < 0 || kind > 2) return fail(HICMI_EINVAL, "kind must be 0 (contacts), 1 (distance) or 2 (similarity)");
+    if (n_sel < 1 || (!order && n_sel != c->n)) return fail(HICMI_EINVAL, "n_sel must be the matrix size when no order is given");
+    HIPCHK(hipSetDevice(c->device));
+    if (kind != 0 && !c->have_sums) { int rc = compute_sums(c); if (rc) return rc; }
+    *d_order_out = nullptr;
+    if (order) {
+        for (int64_t i = 0; i < n_sel; i++) if (order[i] < 0 || order[i] >= c->n) return fail(HICMI_EINVAL, "order entry out of range");
+        int rc = ensure(c->d_plot_order, c->plot_order_cap, n_sel);
+        if (rc) return rc;
+        rc = upload(c, c->d_plot_order, order, sizeof(int32_t) * (size_t)n_sel);
+        if (rc) return rc;
+        *d_order_out = c->d_plot_order;
+    }
+    return HICMI_OK;
+}
+}  // namespace
+
+int hicmi_plot_percentiles(hicmi_ctx* c, int kind, const int32_t* order, int64_t n_sel, const double* q, int64_t n_q,
+                           double* out)
+{
+    // numpy.percentile(a, q) (method "linear") over the n_sel x n_sel cells: virtual index (N-1)*q/100, the two
+    // neighbouring order statistics selected exactly on the device, numpy's _lerp on the host
+    if (!c || !q || !out || n_q < 1) return fail(HICMI_EINVAL, "bad arguments");
+    for (int64_t i = 0; i < n_q; i++) if (!(q[i] >= 0.0 && q[i] <= 100.0)) return fail(HICMI_EINVAL, "percentiles must be in [0, 100]");
+    int32_t* d_order = nullptr;
+    int rc = plot_prepare(c, kind, order, n_sel, &d_order);
+    if (rc) return rc;
+    rc = ensure(c->d_plot_work, c->plot_work_cap, (int64_t)(plot_select_state_bytes() + plot_select_hist_bytes()));
+    if (rc) return rc;
+    SelectState* d_state = reinterpret_cast<SelectState*>(c->d_plot_work);
+    unsigned int* d_hist = reinterpret_cast<unsigned int*>(c->d_plot_work + plot_select_state_bytes());
+    const double N = (double)n_sel * (double)n_sel;
+    const int per_batch = plot_select_max_targets() / 2;
+    std::vector<unsigned char> host(plot_select_state_bytes());
+    for (int64_t q0 = 0; q0 < n_q; q0 += per_batch) {
+        const int nb = (int)std::min<int64_t>(per_batch, n_q - q0);
+        unsigned long long ranks[8];
+        double frac[4];
+        for (int t = 0; t < nb; t++) {
+            const double virt = (N - 1.0) * (q[q0 + t] / 100.0);        // numpy: quantile * (n - 1)
+            double lo = std::floor(virt);
+            if (lo > N - 1.0) lo = N - 1.0;
+            const double hi = std::min(lo + 1.0, N - 1.0);
+            ranks[2 * t] = (unsigned long long)lo; ranks[2 * t + 1] = (unsigned long long)hi;
+            frac[t] = virt - lo;
+        }
+        plot_select_fill(host.data(), ranks, 2 * nb);
+        rc = upload(c, d_state, host.data(), host.size());
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(d_hist, 0, plot_select_hist_bytes(), c->stream));
+        {
+            Timed t(c, F_PLOT, 6.0 * 8.0 * N);
+            launch_plot_select(c->dC, c->ldc, c->d_np, c->d_seq, kind, d_order, (int)n_sel, 2 * nb, d_state, d_hist, c->stream);
+        }
+        HIPCHK(hipGetLastError());
+        rc = download(c, host.data(), d_state, host.size());
+        if (rc) return rc;
+        for (int t = 0; t < nb; t++) {
+            const double a = plot_select_value(host.data(), 2 * t), b = plot_select_value(host.data(), 2 * t + 1), g = frac[t];
+            const double diff = b - a;                                  // numpy.lib._function_base_impl._lerp
+            double v = a + diff * g;
+            if (g >= 0.5) v = b - diff * (1.0 - g);
+            if (diff == 0.0) v = a;
+            out[q0 + t] = v;
+        }
+    }
+    return HICMI_OK;
+}
+
+int hicmi_plot_downsample(hicmi_ctx* c, int kind, const int32_t* order, int64_t n_sel, int64_t px, double* out)
+{
+    if (!c || !out || px < 1 || px > n_sel) return fail(HICMI_EINVAL, "bad arguments (1 <= px <= n_sel)");
+    int32_t* d_order = nullptr;
+    int rc = plot_prepare(c, kind, order, n_sel, &d_order);
+    if (rc) return rc;
+    rc = ensure(c->d_plot_img, c->plot_img_cap, px * px);
+    if (rc) return rc;
+    {
+        Timed t(c, F_PLOT, 8.0 * (double)n_sel * (double)n_sel);
+        launch_plot_downsample(c->dC, c->ldc, c->d_np, c->d_seq, kind, d_order, (int)n_sel, (int)px, c->d_plot_img, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return download(c, out, c->d_plot_img, sizeof(double) * (size_t)(px * px));
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -166,4 +166,16 @@ void launch_insb_diag_cand(const InsStep* steps, int n_chrom, int max_n_used, hi
 void launch_insb_cost(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s);
 void launch_insb_apply(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s);
 
+// k_plot.hip
+void launch_plot_select(const double* C, int64_t ldc, const double* np_sum, const double* seq_sum, int kind,
+                        const int32_t* order, int n_sel, int n_targets, struct SelectState* d_state, unsigned int* d_hist,
+                        hipStream_t s);
+size_t plot_select_state_bytes();
+size_t plot_select_hist_bytes();
+int plot_select_max_targets();
+void plot_select_fill(void* host_state, const unsigned long long* ranks, int n_targets);
+double plot_select_value(const void* host_state, int t);
+void launch_plot_downsample(const double* C, int64_t ldc, const double* np_sum, const double* seq_sum, int kind,
+                            const int32_t* order, int n_sel, int px, double* out, hipStream_t s);
+
 }  // namespace hicmi

@@ -27,6 +27,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import _lib
+from . import plotContactMaps as plotModule
 from .hostio import Bin, initiateLoci, paused_gc, read_contact_matrix, read_contact_matrix_cached  # noqa: F401
 
 SCORE_HOOK = None      # tests: called with the fast scores of every step, in enumeration order
@@ -641,7 +642,7 @@ def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds
     """OG:591-628.  Chromosomes are independent (OG:608-612), so they are ordered concurrently:
     one host thread + one libhicmi context (own HIP stream, own scratch) per chromosome in flight,
     all reading the same device-resident contact matrix.  Results are collected in file order.
-    Plots are not produced."""
+    The per-chromosome figures (OG:615-622) are drawn afterwards from the device-resident matrix."""
     t0 = time.time()
     t0p = time.perf_counter()
     n_workers = 1 if SCORE_HOOK is not None else max(1, min(WORKERS, len(chromList)))
@@ -719,6 +720,29 @@ def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds
             done = dict(pool.map(run, todo))
         fullGenomeOrder = [done[i] for i in range(len(chromList))]
     print("RunTime for total genome = " + str(time.time() - t0))
+    if plotChrom is True and plotModule.plots_enabled(savePlotDir):
+        # OG:615-622: one figure per chromosome.  The device reductions run here one after the other (a context
+        # is not thread-safe), the drawing and PNG encoding on worker threads.
+        where = matrix.bin_index(binList)
+        todo = []
+        for i, chromOrder in enumerate(fullGenomeOrder):
+            rows = [where[b] for s in chromOrder for b in s.binList]
+            if len(rows) == 0:
+                continue
+            img = plotModule.DeviceImage(matrix.ctx, 0, rows)
+            img.prefetch([1, 98], plotModule.figure_pixels(len(rows), 24, 24))
+            todo.append((i, img))
+
+        def draw(item):
+            i, img = item
+            chrName = "Chr_" + str(i + 1)
+            plotModule.plotContactMap(img, resolution=resolution, tickCount=11, highlightChroms=False, wInches=24,
+                                      hInches=24, lP=1, hP=98, reverseColorMap='', showPlot=False,
+                                      savePlot=savePlotDir + "/" + chrName + ".png", title=chrName,
+                                      titleSuffix=plotTitleSuffix)
+        with ThreadPoolExecutor(max_workers=max(1, min(8, len(todo)))) as pool:
+            list(pool.map(draw, todo))
+        print("RunTime for total genome with plotting and saving .pngs = " + str(time.time() - t0))
     return fullGenomeOrder
 
 
@@ -767,17 +791,24 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, chromosomeGroup
     binList = initiateLoci(hicProBedFile, hicProBiasFile, binID_dict=binDict)
     adjMat = buildAdjacencyMatrix(hicProMatrixFile, binList, device=device)
     try:
-        runResident(adjMat, binList, chromosomeGroupFile, chromosomeOrderFile, plotOrderFile, nScaffolds,
-                    scanScaffolds, resolution)
+        orderedChromosomes = runResident(adjMat, binList, chromosomeGroupFile, chromosomeOrderFile, plotOrderFile,
+                                         nScaffolds, scanScaffolds, resolution, savePlotDir=savePlotsDirectory,
+                                         plotTitleSuffix=chromosomePlotSuffix)
+        if plotModule.plots_enabled(fullGenomePlot):                      # OG:700-707
+            where = adjMat.bin_index(binList)
+            rows = [where[b] for group in orderedChromosomes for s in group for b in s.binList]
+            plotModule.plotContactMap(plotModule.DeviceImage(adjMat.ctx, 0, rows), resolution=resolution, tickCount=11,
+                                      highlightChroms=getChromosomeOutlineCoords(orderedChromosomes), wInches=32,
+                                      hInches=32, lP=2, hP=98, reverseColorMap='', showPlot=False,
+                                      savePlot=fullGenomePlot, title=fullGenomePlotTitle, titleSuffix=False)
     finally:
         adjMat.ctx.close()
-    print("- plotting is not part of the MI355X hot path: " + str(fullGenomePlot) + " not written")
     print("Total run-time  for Part2 = " + str(time.time() - t0))
     print("- Part 2 (chromosome ordering) completed successfully")
 
 
 def runResident(adjMat: GenomeMatrix, binList, chromosomeGroupFile, chromosomeOrderFile, plotOrderFile,
-                nScaffolds, scanScaffolds, resolution):
+                nScaffolds, scanScaffolds, resolution, savePlotDir=False, plotTitleSuffix=False):
     """OG:691-709 on contacts that are already resident in HBM (what bench.py times).  ``binList``
     gives the bin of every row of the device matrix; bins that Part 1 did not assign to a group are
     simply never selected, which is what the reference's re-load restricted to grouped bins
@@ -785,7 +816,8 @@ def runResident(adjMat: GenomeMatrix, binList, chromosomeGroupFile, chromosomeOr
     with paused_gc():
         chromosomeList = readChromsFromFile(chromosomeGroupFile)
         orderedChromosomes = orderGenome(adjMat, chromosomeList, binList, resolution, nScaffolds=nScaffolds,
-                                         scanScaffolds=scanScaffolds, plotChrom=True, showPlot=False)
+                                         scanScaffolds=scanScaffolds, plotChrom=True, showPlot=False,
+                                         savePlotDir=savePlotDir, plotTitleSuffix=plotTitleSuffix)
         writeScaffoldOrderingsToFile(orderedChromosomes, chromosomeOrderFile)
         writeBinIDsOrderingToFile([s for group in orderedChromosomes for s in group], plotOrderFile)
     return orderedChromosomes

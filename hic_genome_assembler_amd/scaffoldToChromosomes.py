@@ -18,8 +18,9 @@ heavy step is a hand-written gfx950 kernel reached through the C ABI of include/
 Host control flow (loops over cut candidates, file formats, scaffold voting) is restated here in
 Python because its decisions are sequential and tiny.  There is no CPU fallback for the kernels.
 
-Not implemented: the HMM boundary finder, the Louvain tail
-(``modularity > 0``; unseeded-random in the reference) and PNG plotting.
+Not implemented: the HMM boundary finder and the Louvain tail
+(``modularity > 0``; unseeded-random in the reference).  The two Part 1 figures are drawn from the
+device-resident matrix by plotContactMaps.py (exact percentiles, figure-resolution block means).
 """
 from __future__ import annotations
 
@@ -29,6 +30,7 @@ import time
 import numpy as np
 
 from . import _lib
+from . import plotContactMaps as plotModule
 from .hostio import Bin, initiateLoci, paused_gc, read_contact_matrix, read_contact_matrix_cached  # noqa: F401  (re-exported reference names)
 
 
@@ -429,6 +431,13 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, hicProScaffSize
     try:
         cutIndices = runResident(adjMat, binList, hicProScaffSizeFile, dendrogramOrderFile, binGroupFile,
                                  assessmentFile, chromosomeGroupFile, minSize, modularity, psig)
+        # S2C:1124 / S2C:1156: the clustered distance matrix, then the similarity matrix with the groups outlined
+        if plotModule.plots_enabled(avgClusterPlot):
+            plotModule.plotContactMap(plotModule.DeviceImage(adjMat.ctx, 1, adjMat.order), resolution=resolution,
+                                      highlightChroms=False, showPlot=False, savePlot=avgClusterPlot)
+        if plotModule.plots_enabled(avgClusterPlot_outlined):
+            plotModule.plotContactMap(plotModule.DeviceImage(adjMat.ctx, 2, adjMat.order), resolution=resolution,
+                                      highlightChroms=cutIndices, showPlot=False, savePlot=avgClusterPlot_outlined)
     finally:
         adjMat.ctx.close()
     print("Total run-time of Part1 = " + str(time.time() - t_all))

@@ -216,6 +216,17 @@ int hicmi_p2_scan_pass(hicmi_ctx *ctx, int32_t *ids, uint8_t *rev, int64_t S, in
 int hicmi_p2_insert_all_multi(int64_t n_jobs, hicmi_ctx *const *ctxs, int32_t *const *ids, uint8_t *const *rev,
                               const int64_t *S0, const int32_t *const *new_ids, const int64_t *n_new, double *best_out);
 
+/* ---- plot support -----------------------------------------------------------------------------
+ * plotContactMap (plotContactMaps.py:15-91) colours every cell of an N x N matrix between two
+ * numpy.percentile limits.  The matrix stays on the device: kind 0 = raw contacts (Part 2 plots,
+ * OG:619,704), 1 = distance transform (S2C:147 -> S2C:1124), 2 = similarity transform (S2C:149 ->
+ * S2C:1156); order = the n_sel matrix rows shown, in plot order (NULL: all rows as stored).
+ * hicmi_plot_percentiles: out[i] = numpy.percentile(cells, q[i]) (method "linear"), exact.
+ * hicmi_plot_downsample: out = px x px block means (row-major fp64), px <= n_sel. */
+int hicmi_plot_percentiles(hicmi_ctx *ctx, int kind, const int32_t *order, int64_t n_sel, const double *q, int64_t n_q,
+                           double *out);
+int hicmi_plot_downsample(hicmi_ctx *ctx, int kind, const int32_t *order, int64_t n_sel, int64_t px, double *out);
+
 /* ---- timing ----------------------------------------------------------------------------------
  * Accumulated device time (HIP events on the context stream) per kernel family since the last
  * reset, for bench.py's roofline object.  names_out: caller buffer receiving ';'-separated names;

@@ -36,6 +36,31 @@ class OracleContext:
         leaves, z = orc.average_cluster_leaves(orc.to_distance(self.mat))
         return leaves, z
 
+    # ---- plot support: NumPy restatement of hicmi_plot_percentiles / hicmi_plot_downsample
+    def plot_matrix(self, kind, order):
+        m = self.mat
+        if kind >= 1:
+            m = orc.to_distance(self.mat)
+        if kind == 2:
+            m = orc.seq_row_sums(self.mat)[:, None] * (1.0 - (m - 1.0))
+        if order is not None:
+            o = np.asarray(order, dtype=np.int64)
+            m = m[np.ix_(o, o)]
+        return m
+
+    def plot_percentiles(self, kind, order, q):
+        return np.percentile(self.plot_matrix(kind, order), q)
+
+    def plot_downsample(self, kind, order, px):
+        m = self.plot_matrix(kind, order)
+        n = len(m)
+        edges = (np.arange(px + 1, dtype=np.int64) * n) // px
+        out = np.empty((px, px))
+        for r in range(px):
+            for c in range(px):
+                out[r, c] = m[edges[r]:edges[r + 1], edges[c]:edges[c + 1]].mean()
+        return out
+
     def rank_matrix(self, order):
         order = np.asarray(order, dtype=np.int64)
         dist = orc.to_distance(self.mat)[:, order][order]

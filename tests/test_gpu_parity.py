@@ -517,3 +517,61 @@ def test_full_size_properties(hic, n):
             R = ctx.rank_rows(i, 1)[0].astype(np.int64)
             pr = R[:i]
             assert x[i] == np.count_nonzero((pr >= 0) & (pr <= i))
+
+
+def test_plot_percentiles_and_downsample(hic):
+    """the colour limits are numpy.percentile itself (exact order statistics selected on the
+    device + NumPy's interpolation), the picture the block means of the transformed, permuted matrix."""
+    rng = np.random.default_rng(21)
+    for name in ("n300_edges", "n600"):
+        spec, meta, gold, lay, c = gc.load_case(name)
+        n = len(c)
+        with hic.Context(0) as ctx:
+            ctx.set_contacts(c)
+            np_sum, seq_sum = ctx.row_sums()
+            if np.any(np_sum == 0):                                   # the edge-case fixture has empty bins (S2C:100-136)
+                keep = np.flatnonzero(np_sum != 0)
+                ctx.compact(keep)
+                c = np.ascontiguousarray(c[np.ix_(keep, keep)])
+                n = len(c)
+                np_sum, seq_sum = ctx.row_sums()
+            dist = (1.0 - c / np_sum[:, None]) + 1.0
+            sim = seq_sum[:, None] * (1.0 - (dist - 1.0))
+            perm = rng.permutation(n).astype(np.int32)
+            sub = np.sort(rng.choice(n, size=n // 3, replace=False)).astype(np.int32)[::-1].copy()
+            for kind, mat in ((0, c), (1, dist), (2, sim)):
+                for order in (None, perm, sub):
+                    view = mat if order is None else mat[np.ix_(order, order)]
+                    q = [1, 98] if kind else [2, 98]
+                    got = ctx.plot_percentiles(kind, order, q + [0, 100, 50, 33.3])
+                    want = np.percentile(view, q + [0, 100, 50, 33.3])
+                    assert np.array_equal(got, want), (name, kind, got, want)
+                    m = len(view)
+                    for px in (m, 7, 64):
+                        img = ctx.plot_downsample(kind, order, px)
+                        edges = (np.arange(px + 1, dtype=np.int64) * m) // px
+                        rows = np.add.reduceat(view, edges[:-1], axis=0)
+                        blocks = np.add.reduceat(rows, edges[:-1], axis=1)
+                        cnt = np.diff(edges)
+                        assert np.allclose(img, blocks / (cnt[:, None] * cnt[None, :]), rtol=1e-12, atol=0), (name, kind, px)
+
+
+def test_cli_writes_plots(hic, tmp_path, monkeypatch):
+    """The drop-in run leaves the reference's plot files (avgCluster, outlined, Chr_i, full genome) next to
+    the text outputs, which stay identical to the golden ones."""
+    from hic_genome_assembler_amd import run_hicAssembler, synth
+    monkeypatch.delenv("HICMI_NO_PLOTS", raising=False)
+    name = "n300_edges"
+    spec, meta, gold, lay, c = gc.load_case(name)
+    paths = gc.write_case_files(name, str(tmp_path))
+    cfg = synth.write_config(str(tmp_path / "config.txt"), paths, str(tmp_path / "out"), str(tmp_path / "plots"),
+                             lay.resolution, min_size=spec["min_size"], modularity=0.0, psig=spec["psig"],
+                             n_scaffolds=spec["n_scaffolds"], scan_scaffolds=spec["scan_scaffolds"])
+    run_hicAssembler.main(["-part1", "-part2", "-c", cfg])
+    for fn in gc.OUTPUT_FILES:
+        with open(str(tmp_path / "out" / fn)) as fh:
+            assert fh.read() == gc.golden_text(name, fn), fn
+    pngs = sorted(p for p in os.listdir(str(tmp_path / "plots")) if p.endswith(".png"))
+    assert len(pngs) >= 4 and any(p.startswith("Chr_1") for p in pngs), pngs
+    for p in pngs:
+        assert os.path.getsize(str(tmp_path / "plots" / p)) > 10000, p
