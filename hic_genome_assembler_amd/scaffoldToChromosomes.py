@@ -18,8 +18,8 @@ heavy step is a hand-written gfx950 kernel reached through the C ABI of include/
 Host control flow (loops over cut candidates, file formats, scaffold voting) is restated here in
 Python because its decisions are sequential and tiny.  There is no CPU fallback for the kernels.
 
-Not implemented: the HMM boundary finder and the Louvain tail
-(``modularity > 0``; unseeded-random in the reference).  The two Part 1 figures are drawn from the
+Not implemented: the HMM boundary finder.  The Louvain tail (``modularity > 0``,
+unseeded-random in the reference) is a seeded restatement in modularity.py.  The two Part 1 figures are drawn from the
 device-resident matrix by plotContactMaps.py (exact percentiles, figure-resolution block means).
 """
 from __future__ import annotations
@@ -30,6 +30,7 @@ import time
 import numpy as np
 
 from . import _lib
+from . import modularity as louvain
 from . import plotContactMaps as plotModule
 from .hostio import Bin, initiateLoci, paused_gc, read_contact_matrix, read_contact_matrix_cached  # noqa: F401  (re-exported reference names)
 
@@ -423,20 +424,19 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, hicProScaffSize
     if hyperGeom is not True:
         raise NotImplementedError("only the hyperGeom = True strategy is implemented on MI355X "
                                   "(hmm needs hmmlearn's stochastic EM; SURVEY.md section 2 row 7)")
-    if modularity is not False and modularity > 0.0:
-        raise NotImplementedError("modularity > 0 (Louvain tail, unseeded random in the reference, S2C:253) "
-                                  "is not implemented: set `modularity = 0`")
     binList = initiateLoci(hicProBedFile, hicProBiasFile)
     adjMat = buildAdjacencyMatrix(hicProMatrixFile, binList, device=device)
     try:
         cutIndices = runResident(adjMat, binList, hicProScaffSizeFile, dendrogramOrderFile, binGroupFile,
-                                 assessmentFile, chromosomeGroupFile, minSize, modularity, psig)
-        # S2C:1124 / S2C:1156: the clustered distance matrix, then the similarity matrix with the groups outlined
+                                 assessmentFile, chromosomeGroupFile, minSize, modularity, psig,
+                                 louvainRounds=louvainRounds)
+        # S2C:1124 / S2C:1155-1156: the clustered distance matrix, then - groups outlined - the distance transform of
+        # the un-logged similarity matrix, which is the distance matrix again up to a few roundings
         if plotModule.plots_enabled(avgClusterPlot):
             plotModule.plotContactMap(plotModule.DeviceImage(adjMat.ctx, 1, adjMat.order), resolution=resolution,
                                       highlightChroms=False, showPlot=False, savePlot=avgClusterPlot)
         if plotModule.plots_enabled(avgClusterPlot_outlined):
-            plotModule.plotContactMap(plotModule.DeviceImage(adjMat.ctx, 2, adjMat.order), resolution=resolution,
+            plotModule.plotContactMap(plotModule.DeviceImage(adjMat.ctx, 1, adjMat.order), resolution=resolution,
                                       highlightChroms=cutIndices, showPlot=False, savePlot=avgClusterPlot_outlined)
     finally:
         adjMat.ctx.close()
@@ -446,7 +446,7 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, hicProScaffSize
 
 
 def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOrderFile, binGroupFile,
-                assessmentFile, chromosomeGroupFile, minSize, modularity, psig):
+                assessmentFile, chromosomeGroupFile, minSize, modularity, psig, louvainRounds=20):
     """S2C:1117-1167 on a contact map that is already resident in HBM (what bench.py times): every
     stage after the text loaders, including the small intermediate files the reference round-trips
     through.  Returns the filtered cut indices; ``binList`` is left in .bed order for the caller."""
@@ -467,6 +467,16 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
         initial_cut_inds = pre_process_all_matrix_breakpoints(argsorted_adjMat, min_size=minSize,
                                                               min_frac=modularity, psig=psig)
         cutIndices = filter_noisy_breakpoints(argsorted_adjMat, initial_cut_inds, psig=psig)
+        if modularity is not False and modularity > 0.0:
+            # S2C:1148-1152: Louvain on log10(similarity + 1) of the bins after the last cut index (modularity.py:
+            # seeded restatement of python-louvain; the cells come from the device in the current order)
+            start = sorted(cutIndices)[-1] if len(cutIndices) else 0
+            tail_rows = list(adjMat.order[start:])
+            if len(tail_rows) > 0:
+                sim_tail = adjMat.ctx.plot_downsample(2, tail_rows, len(tail_rows))
+                new_order, cutIndices = louvain.modularity_remaining_data(louvain.log_transform(sim_tail), binList,
+                                                                          cutIndices, n_rounds=louvainRounds)
+                adjMat, binList = reorderMatrix(adjMat, binList, new_order)
         binGroups = writeBinGroupingsToFile(cutIndices, binList, binGroupFile)
         print("Total run-time to identify chromosome boundaries = " + str(time.time() - t0))
         t0 = time.time()

@@ -575,3 +575,28 @@ def test_cli_writes_plots(hic, tmp_path, monkeypatch):
     assert len(pngs) >= 4 and any(p.startswith("Chr_1") for p in pngs), pngs
     for p in pngs:
         assert os.path.getsize(str(tmp_path / "plots" / p)) > 10000, p
+
+
+def test_louvain_tail_same_on_gpu_and_oracle(hic, tmp_path, monkeypatch):
+    """modularity = .05 (the reference's shipped default): the tail's similarity cells come from the device;
+    with the same seed the GPU run and the oracle-backed run must write the same groups (the Louvain code is
+    host-side and deterministic, so this pins the device-side inputs of SURVEY 8f N3)."""
+    from fake_context import OracleContext
+    from hic_genome_assembler_amd import _lib, scaffoldToChromosomes as p1
+    name = "n400_default"
+    spec, meta, gold, lay, c = gc.load_case(name)
+    paths = gc.write_case_files(name, str(tmp_path))
+    texts = {}
+    for run in ("gpu", "oracle"):
+        if run == "oracle":
+            monkeypatch.setattr(_lib, "Context", OracleContext)
+        out = tmp_path / run
+        out.mkdir()
+        f = lambda k: str(out / k)  # noqa: E731
+        p1.runPipeline(paths["hicProBedFile"], paths["hicProBiasFile"], paths["hicProMatrixFile"],
+                       paths["hicProScaffSizeFile"], f("dendrogramOrder.txt"), False, False, f("binGroups.txt"),
+                       f("assessment.txt"), f("chromosomeGroups.txt"), True, False, spec["min_size"], 0.05, 4,
+                       spec["psig"], 5, 5, lay.resolution)
+        texts[run] = [open(f(k)).read() for k in ("binGroups.txt", "assessment.txt", "chromosomeGroups.txt")]
+    assert texts["gpu"] == texts["oracle"]
+    assert texts["gpu"][0].count("### Chromosome group") >= 2
