@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_p2_base_partial(const double* __restric
     base_partial_body(M2, ld2, p, n_arr, H, n_tot, blockIdx.x, gridDim.x, partial + blockIdx.x);
 }
 
-static std::atomic<int> g_lds_base{0}, g_lds_straddle{0}, g_lds_cross{0}, g_lds_wdelta{0}, g_lds_insb_base{0}, g_lds_insb_fast{0};
+static std::atomic<int> g_lds_base{0}, g_lds_straddle{0}, g_lds_cross{0}, g_lds_wdelta{0}, g_lds_wdelta1{0}, g_lds_wdelta_blk{0}, g_lds_wG{0}, g_lds_insb_base{0}, g_lds_insb_fast{0};
 
 // BASE as partial sums over row slabs: out[0..n_blocks)
 void launch_p2_base_partial(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const double* H, int n_tot,
@@ -276,11 +276,13 @@ void launch_insb_fast(const InsStep* steps, int n_chrom, int max_S, int max_n_ar
 static constexpr int G_TILE = 2048;
 static constexpr int G_TMAX = 8;                        // up to 512 window bins per pass
 
+template <bool H_IN_LDS>
 __global__ __launch_bounds__(256) void k_p2_window_G(const double* __restrict__ M2, int64_t ld2,
                                                      const int32_t* __restrict__ pos2sel, int n,
                                                      const WindowBatchEntry* __restrict__ wb,
-                                                     const double* __restrict__ H, double* __restrict__ G_all)
+                                                     const double* H, double* __restrict__ G_all)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
     __shared__ double vals[G_TILE];
     __shared__ double part[4][64];
     const WindowBatchEntry& we = wb[blockIdx.y];
@@ -290,6 +292,12 @@ __global__ __launch_bounds__(256) void k_p2_window_G(const double* __restrict__ 
     double* __restrict__ G = G_all + we.g_off;
     const double* __restrict__ row = M2 + (int64_t)pos2sel[p0 + x] * ld2;
     const double hn = H[n - 1];
+    if (H_IN_LDS) {                                         // the harmonic table is read once per multiply-add
+        double* hl = reinterpret_cast<double*>(smem_g);
+        for (int i = tid; i < n; i += 256) hl[i] = H[i];
+        __syncthreads();
+        H = hl;
+    }
     const int n_out = n - m;
     for (int tbase = 0; tbase < m; tbase += 64 * G_TMAX) {
         double acc[G_TMAX];
@@ -334,45 +342,95 @@ __global__ __launch_bounds__(256) void k_p2_window_G(const double* __restrict__ 
 // block = (candidate, window).  Slot j of the candidate holds window scaffold jj = orders[o][j] laid
 // down reversed iff orients[r][j]; a bin's window-local index x is its offset inside the CURRENT
 // window layout (that is how G is indexed).
-__global__ __launch_bounds__(64) void k_p2_window_delta(const double* __restrict__ M2, int64_t ld2, int n, int k,
-                                                        const WindowBatchEntry* __restrict__ wb,
-                                                        const int8_t* __restrict__ orders,
-                                                        const uint8_t* __restrict__ orients, int n_ori,
-                                                        const double* __restrict__ H, const double* __restrict__ G_all,
-                                                        double* __restrict__ delta_all)
+static constexpr int WD_PER_WAVE = 4;                    // candidates a wave scores one after the other
+// WD_WAVES = 4: 16 candidates per 256-lane workgroup (single-wave workgroups made the launch rate the
+// bottleneck: 61,000 of them per batch); WD_WAVES = 1 keeps windows of more than 4096 bins within the LDS.
+// BLOCK_IN_LDS (windows of at most 128 bins): the window's m x m block of the matrix, in the window's current
+// layout, is staged in LDS once per workgroup - all 1920 candidates of a window read the same 34 KB block in a
+// different order, which otherwise comes out of L2 once per candidate (2.3 GB per batch of 32 windows).
+template <int WD_WAVES, bool BLOCK_IN_LDS>
+__global__ __launch_bounds__(WD_WAVES * 64) void k_p2_window_delta(const double* __restrict__ M2, int64_t ld2, int n, int k,
+                                                         const WindowBatchEntry* __restrict__ wb,
+                                                         const int8_t* __restrict__ orders,
+                                                         const uint8_t* __restrict__ orients, int n_ori, int n_cand,
+                                                         const double* __restrict__ H, const double* __restrict__ G_all,
+                                                         double* __restrict__ delta_all,
+                                                         const int32_t* __restrict__ pos2sel, int max_m)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // the window's scaffolds (once per workgroup) and each wave's candidate order / orientation row live in LDS:
+    // private arrays indexed at run time would be placed in scratch memory
+    __shared__ int s_start[8], s_len[8], s_off[8], s_rev[8];
+    __shared__ int s_ord[WD_WAVES][8], s_ori[WD_WAVES][8], s_slot[WD_WAVES][9];
     const WindowBatchEntry& we = wb[blockIdx.y];
-    const WindowDesc& w = we.w;
     const int m = we.m;
     const double* __restrict__ G = G_all + we.g_off;
-    int32_t* useq = reinterpret_cast<int32_t*>(smem);          // selection index at slot t
-    int32_t* xseq = useq + m;                                   // window-local index at slot t
-    const int c = blockIdx.x, lane = threadIdx.x;
-    const int8_t* __restrict__ ord = orders + (int64_t)(c / n_ori) * k;
-    const uint8_t* __restrict__ ori = orients + (int64_t)(c % n_ori) * k;
-    int slot_off[9];
-    slot_off[0] = 0;
-    for (int j = 0; j < k; j++) slot_off[j + 1] = slot_off[j] + w.len[ord[j]];
-    for (int t = lane; t < m; t += 64) {
-        int j = 0;
-        while (j + 1 < k && slot_off[j + 1] <= t) j++;
-        const int jj = ord[j], len = w.len[jj];
-        const int ep = t - slot_off[j];
-        const int e = ori[j] ? len - 1 - ep : ep;              // offset inside the scaffold, selection order
-        useq[t] = w.start[jj] + e;
-        xseq[t] = w.off[jj] + (w.rev[jj] ? len - 1 - e : e);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t* useq = reinterpret_cast<int32_t*>(smem) + (int64_t)wave * 2 * m;     // selection index at slot t
+    int32_t* xseq = useq + m;                                                    // window-local index at slot t
+    double* wt = reinterpret_cast<double*>(smem + (((size_t)max_m * 2 * WD_WAVES * sizeof(int32_t) + 15) & ~(size_t)15));
+    double* wblk = wt + max_m;                               // wt[d] = H[n-1] - H[d-1], the weight of a pair d slots apart
+    if (tid < k) {
+        s_start[tid] = we.w.start[tid]; s_len[tid] = we.w.len[tid]; s_off[tid] = we.w.off[tid]; s_rev[tid] = we.w.rev[tid];
     }
-    __syncthreads();
+    if (BLOCK_IN_LDS) {
+        const int32_t* __restrict__ wsel = pos2sel + we.p0;                      // selection index of window bin x
+        for (int e = tid; e < m * m; e += WD_WAVES * 64) {
+            const int x = e / m, y = e - x * m;
+            wblk[e] = M2[(int64_t)wsel[x] * ld2 + wsel[y]];
+        }
+    }
     const double hn = H[n - 1];
-    double acc = 0.0;
-    for (int t = lane; t < m; t += 64) acc += G[(int64_t)xseq[t] * m + t];
-    for (int s = 0; s < m - 1; s++) {
-        const double* __restrict__ row = M2 + (int64_t)useq[s] * ld2;
-        for (int t = s + 1 + lane; t < m; t += 64) acc += row[useq[t]] * (hn - H[t - s - 1]);
+    for (int d = tid; d < m; d += WD_WAVES * 64) wt[d] = d ? hn - H[d - 1] : 0.0;    // wt[0] = 0 mutes the lower half
+    const int mm = m * m, ds = 64 / m, dt = 64 - ds * m;
+    for (int it = 0; it < WD_PER_WAVE; it++) {
+        const int c = (blockIdx.x * WD_WAVES + wave) * WD_PER_WAVE + it;
+        const bool live = c < n_cand;
+        if (live && lane < k) {
+            s_ord[wave][lane] = orders[(int64_t)(c / n_ori) * k + lane];
+            s_ori[wave][lane] = orients[(int64_t)(c % n_ori) * k + lane];
+        }
+        __syncthreads();
+        if (live && lane == 0) {
+            int acc_len = 0;
+            s_slot[wave][0] = 0;
+            for (int j = 0; j < k; j++) { acc_len += s_len[s_ord[wave][j]]; s_slot[wave][j + 1] = acc_len; }
+        }
+        __syncthreads();
+        if (live) {
+            for (int t = lane; t < m; t += 64) {
+                int j = 0;
+                while (j + 1 < k && s_slot[wave][j + 1] <= t) j++;
+                const int jj = s_ord[wave][j], len = s_len[jj];
+                const int ep = t - s_slot[wave][j];
+                const int e = s_ori[wave][j] ? len - 1 - ep : ep;      // offset inside the scaffold, selection order
+                useq[t] = s_start[jj] + e;
+                xseq[t] = s_off[jj] + (s_rev[jj] ? len - 1 - e : e);
+            }
+        }
+        __syncthreads();
+        if (live) {
+            double acc = 0.0;
+            for (int t = lane; t < m; t += 64) acc += G[(int64_t)xseq[t] * m + t];
+            // pairs inside the window: the m x m grid is walked flat (s = q / m, t = q % m kept up to date by
+            // carries).  No branch in the body - the lower half is multiplied by wt[0] = 0 - so that the eight
+            // unrolled trips issue their index, matrix and weight loads together instead of one dependent chain
+            // per trip.
+            int ps = lane / m, pt = lane - ps * m;
+#pragma unroll 8
+            for (int q = lane; q < mm; q += 64) {
+                const double v = BLOCK_IN_LDS ? wblk[xseq[ps] * m + xseq[pt]] : M2[(int64_t)useq[ps] * ld2 + useq[pt]];
+                acc += v * wt[pt > ps ? pt - ps : 0];
+                const int npt = pt + dt;
+                const bool carry = npt >= m;
+                ps += ds + (carry ? 1 : 0);
+                pt = carry ? npt - m : npt;
+            }
+            acc = wave_sum_s(acc);
+            if (lane == 0) delta_all[(int64_t)blockIdx.y * n_cand + c] = acc;
+        }
+        __syncthreads();
     }
-    acc = wave_sum_s(acc);
-    if (lane == 0) delta_all[(int64_t)blockIdx.y * gridDim.x + c] = acc;
 }
 
 // one launch pair for n_win windows described by the device array wb; max_m = largest window (bins)
@@ -381,11 +439,31 @@ void launch_p2_window_batch(const double* M2, int64_t ld2, const int32_t* pos2se
                             int n_ord, int n_ori, const double* H, double* G_all, double* delta_all, hipStream_t s)
 {
     if (n_win <= 0 || max_m <= 0) return;
-    hipLaunchKernelGGL(k_p2_window_G, dim3(max_m, n_win), dim3(256), 0, s, M2, ld2, pos2sel, n, wb, H, G_all);
-    size_t lds = (((size_t)max_m * 2 * sizeof(int32_t)) + 15) & ~(size_t)15;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_window_delta), g_lds_wdelta, lds);
-    hipLaunchKernelGGL(k_p2_window_delta, dim3(n_ord * n_ori, n_win), dim3(64), lds, s, M2, ld2, n, k, wb, orders, orients,
-                       n_ori, H, G_all, delta_all);
+    const size_t h_lds = (((size_t)n * sizeof(double)) + 15) & ~(size_t)15;
+    if (h_lds <= 96 * 1024) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_window_G<true>), g_lds_wG, h_lds);
+        hipLaunchKernelGGL(k_p2_window_G<true>, dim3(max_m, n_win), dim3(256), h_lds, s, M2, ld2, pos2sel, n, wb, H, G_all);
+    } else {
+        hipLaunchKernelGGL(k_p2_window_G<false>, dim3(max_m, n_win), dim3(256), 0, s, M2, ld2, pos2sel, n, wb, H, G_all);
+    }
+    const int n_cand = n_ord * n_ori;
+    const size_t wt_bytes = (size_t)max_m * sizeof(double);
+    const size_t seq4 = ((((size_t)max_m * 2 * 4 * sizeof(int32_t)) + 15) & ~(size_t)15) + wt_bytes;
+    if (max_m <= 128) {
+        const size_t lds = seq4 + (size_t)max_m * max_m * sizeof(double);
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_window_delta<4, true>), g_lds_wdelta_blk, lds);
+        hipLaunchKernelGGL((k_p2_window_delta<4, true>), dim3((n_cand + 4 * WD_PER_WAVE - 1) / (4 * WD_PER_WAVE), n_win), dim3(256),
+                           lds, s, M2, ld2, n, k, wb, orders, orients, n_ori, n_cand, H, G_all, delta_all, pos2sel, max_m);
+    } else if (max_m <= 4096) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_window_delta<4, false>), g_lds_wdelta, seq4);
+        hipLaunchKernelGGL((k_p2_window_delta<4, false>), dim3((n_cand + 4 * WD_PER_WAVE - 1) / (4 * WD_PER_WAVE), n_win), dim3(256),
+                           seq4, s, M2, ld2, n, k, wb, orders, orients, n_ori, n_cand, H, G_all, delta_all, pos2sel, max_m);
+    } else {
+        const size_t lds = ((((size_t)max_m * 2 * sizeof(int32_t)) + 15) & ~(size_t)15) + wt_bytes;
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_window_delta<1, false>), g_lds_wdelta1, lds);
+        hipLaunchKernelGGL((k_p2_window_delta<1, false>), dim3((n_cand + WD_PER_WAVE - 1) / WD_PER_WAVE, n_win), dim3(64), lds, s, M2,
+                           ld2, n, k, wb, orders, orients, n_ori, n_cand, H, G_all, delta_all, pos2sel, max_m);
+    }
 }
 
 }  // namespace hicmi
