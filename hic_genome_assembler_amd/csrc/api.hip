@@ -972,6 +972,9 @@ int window_batch(hicmi_ctx* c, int64_t first0, int64_t count, int64_t k, double*
         g_bytes += 8.0 * (double)e.m * (double)(c->n_arr - e.m);
         d_bytes += 8.0 * (double)n_cand * (0.5 * (double)e.m * (double)(e.m - 1) + (double)e.m);
     }
+    // placement tables (k_part2_window.hip) unless the direct per-candidate kernels are asked for (A/B switch)
+    static const bool direct = getenv("HICMI_P2_WINDOW_DIRECT") != nullptr;
+    if (!direct) g_total = count * window_table_doubles((int)k);
     int rc = ensure(c->d_G, c->g_cap, g_total);
     if (rc) return rc;
     rc = ensure(c->d_delta, c->delta_cap, n_cand * count);
@@ -984,8 +987,13 @@ int window_batch(hicmi_ctx* c, int64_t first0, int64_t count, int64_t k, double*
         // the G and delta kernels are launched as a pair; their algorithmic bytes are booked separately
         c->launches[F_P2_WINDOW_DELTA]++; c->bytes[F_P2_WINDOW_DELTA] += d_bytes;
         Timed t(c, F_P2_WINDOW_G, g_bytes);
-        launch_p2_window_batch(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, (int)k, c->d_wb, (int)count, max_m, c->d_orders,
-                               c->d_orients, (int)c->n_orders, (int)c->n_orients, c->d_H, c->d_G, c->d_delta, c->stream);
+        if (direct)
+            launch_p2_window_batch(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, (int)k, c->d_wb, (int)count, max_m, c->d_orders,
+                                   c->d_orients, (int)c->n_orders, (int)c->n_orients, c->d_H, c->d_G, c->d_delta, c->stream);
+        else
+            launch_p2_window_tables(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, (int)k, c->d_wb, (int)count, max_m,
+                                    c->d_orders, c->d_orients, (int)c->n_orders, (int)c->n_orients, c->d_H, c->d_G, c->d_delta,
+                                    c->stream);
     }
     HIPCHK(hipGetLastError());
     rc = download(c, delta_out, c->d_delta, sizeof(double) * (size_t)(n_cand * count));

@@ -137,6 +137,13 @@ void launch_p2_window_batch(const double* M2, int64_t ld2, const int32_t* pos2se
                             int n_ord, int n_ori, const double* H, double* G_all, double* delta_all, hipStream_t s);
 
 
+// k_part2_window.hip: the same scores from placement tables (one pass over the matrix per table, a few look-ups
+// per candidate); tables = n_win * window_table_doubles(k) doubles of scratch
+int64_t window_table_doubles(int k);
+void launch_p2_window_tables(const double* M2, int64_t ld2, const int32_t* pos2sel, int n, int k,
+                             const WindowBatchEntry* wb, int n_win, int max_m, const int8_t* orders, const uint8_t* orients,
+                             int n_ord, int n_ori, const double* H, double* tables, double* delta_all, hipStream_t s);
+
 // Lock-step insertion (k_part2_insert.hip): orderRemainderScaffolds for several chromosomes at once, every
 // decision taken on the device.  One InsStep per (step, chromosome), built by the host in advance.
 static constexpr int INS_MAXC = 8;       // candidates re-scored literally per step; more -> the host decides that step

@@ -1,0 +1,250 @@
+// k_part2_window.hip - window scoring by PLACEMENT TABLES (bruteForceBestScore orderGenome.py:432-473,
+// scanOrdering :495-549): all k!/2 * 2^k orders x orientations of a window of k scaffolds.
+//
+// With w(d) = H[n-1] - H[d-1], the part of  score * total  that differs between candidates is
+//     sum over window scaffolds j            of  Q[j][r_j][B_j]        pairs (bin of j, bin outside the window)
+//   + sum over window scaffold pairs a -> b  of  P[a][b][r_a][r_b][G_ab] pairs (bin of a, bin of b), a placed first
+//   + a constant (pairs inside one scaffold: a reversal keeps their distances)
+// where r = orientation, B_j = the SET of window scaffolds placed before j (it fixes j's offset) and
+// G_ab = the set placed between a and b (it fixes their gap).  A set is a k-bit mask, so the tables have
+//   Q: k * 2 * 2^(k-1)   and   P: k(k-1) * 4 * 2^(k-2)   entries
+// (k = 5: 160 + 640; k = 6: 384 + 1920) against 1,920 / 23,040 candidates that each used to walk all m^2/2
+// pairs of the window: the matrix is read once per table, and a candidate is k + k(k-1)/2 look-ups.
+// For the brute-force step over the six largest scaffolds this is ~180x fewer multiply-adds, and it no
+// longer grows with (number of candidates) x (window bins)^2.
+//
+// Only differences between candidates of a step reach a decision, and the winners are re-scored literally
+// (k_p2_diag_sums), so the summation order of these tables never reaches an output.
+#include "hicmi_internal.h"
+
+namespace hicmi {
+
+__device__ __forceinline__ double wave_sum_w(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// per-window table layout (doubles): [Q: WT_SLICES x (k*2 << k)][P: k*k*4 << k][C: 8].  Q is accumulated in
+// WT_SLICES slices of the outside positions by separate workgroups (5 x 32 workgroups per batch would leave
+// most of the chip idle) and the slices are added, in order, when a candidate looks an entry up.
+static constexpr int WT_SLICES = 8;
+__host__ __device__ inline int64_t wt_q_size(int k) { return ((int64_t)k * 2) << k; }
+__host__ __device__ inline int64_t wt_p_size(int k) { return ((int64_t)k * k * 4) << k; }
+int64_t window_table_doubles(int k) { return WT_SLICES * wt_q_size(k) + wt_p_size(k) + 8; }
+
+static constexpr int WT_ACC = 8;                        // table entries a wave accumulates per pass over the data
+
+// insert a zero bit at position b (b below the current width)
+__device__ __forceinline__ int spread_bit(int v, int b) { return ((v >> b) << (b + 1)) | (v & ((1 << b) - 1)); }
+
+// ---- Q: window scaffold j against everything outside the window -------------------------------------------------
+// workgroup = (scaffold j, window); wave w takes entries w*8 .. w*8+7, then +32, ...; lanes sweep the outside
+// positions; every matrix element read feeds 8 table entries.
+template <bool H_IN_LDS>
+__global__ __launch_bounds__(256) void k_win_outside(const double* __restrict__ M2, int64_t ld2,
+                                                     const int32_t* __restrict__ pos2sel, int n, int k,
+                                                     const WindowBatchEntry* __restrict__ wb, const double* H,
+                                                     double* __restrict__ tables, int64_t table_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+    __shared__ int s_len[8], s_glen[256];
+    const WindowBatchEntry& we = wb[blockIdx.y];
+    const int j = blockIdx.x, p0 = we.p0, m = we.m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < k) s_len[tid] = we.w.len[tid];
+    const double hn = H[n - 1];
+    if (H_IN_LDS) {
+        double* hl = reinterpret_cast<double*>(smem_w);
+        for (int i = tid; i < n; i += 256) hl[i] = H[i];
+        H = hl;
+    }
+    __syncthreads();
+    if (tid < (1 << k)) {
+        int g = 0;
+        for (int b = 0; b < k; b++) if ((tid >> b) & 1) g += s_len[b];
+        s_glen[tid] = g;
+    }
+    __syncthreads();
+    const int Lj = s_len[j], startj = we.w.start[j], n_out = n - m;
+    const int q_lo = (int)(((int64_t)blockIdx.z * n_out) / WT_SLICES), q_hi = (int)(((int64_t)(blockIdx.z + 1) * n_out) / WT_SLICES);
+    double* __restrict__ Q = tables + (int64_t)blockIdx.y * table_stride + blockIdx.z * wt_q_size(k) + (((int64_t)j * 2) << k);
+    const int n_entries = 2 << (k - 1);                     // (orientation, set of the other k-1 scaffolds)
+    for (int e0 = wave * WT_ACC; e0 < n_entries; e0 += 4 * WT_ACC) {
+        double acc[WT_ACC];
+        int off[WT_ACC], rev[WT_ACC];
+#pragma unroll
+        for (int u = 0; u < WT_ACC; u++) {
+            const int e = e0 + u < n_entries ? e0 + u : n_entries - 1;
+            rev[u] = e >> (k - 1);
+            off[u] = p0 + s_glen[spread_bit(e & ((1 << (k - 1)) - 1), j)];
+            acc[u] = 0.0;
+        }
+        for (int i = 0; i < Lj; i++) {
+            const double* __restrict__ row = M2 + (int64_t)(startj + i) * ld2;
+#pragma unroll 2
+            for (int qq = q_lo + lane; qq < q_hi; qq += 64) {
+                const int pos = qq < p0 ? qq : qq + m;      // positions outside the window keep their place
+                const double v = row[pos2sel[pos]];
+#pragma unroll
+                for (int u = 0; u < WT_ACC; u++) {
+                    const int slot = off[u] + (rev[u] ? Lj - 1 - i : i);
+                    const int d = slot > pos ? slot - pos : pos - slot;
+                    acc[u] += v * (hn - H[d - 1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WT_ACC; u++) {
+            const double sum = wave_sum_w(acc[u]);
+            const int e = e0 + u;
+            if (lane == 0 && e < n_entries)
+                Q[((int64_t)(e >> (k - 1)) << k) | spread_bit(e & ((1 << (k - 1)) - 1), j)] = sum;
+        }
+    }
+}
+
+// ---- P: window scaffold a placed before b; C: pairs inside one scaffold ------------------------------------------
+// workgroup = (a * k + b, window).  Every element of the La x Lb block feeds 8 entries per pass.
+template <bool H_IN_LDS>
+__global__ __launch_bounds__(256) void k_win_pairs(const double* __restrict__ M2, int64_t ld2, int n, int k,
+                                                   const WindowBatchEntry* __restrict__ wb, const double* H,
+                                                   double* __restrict__ tables, int64_t table_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+    __shared__ int s_len[8], s_glen[256];
+    __shared__ double s_part[4];
+    const WindowBatchEntry& we = wb[blockIdx.y];
+    const int a = blockIdx.x / k, b = blockIdx.x - a * k, m = we.m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < k) s_len[tid] = we.w.len[tid];
+    const double hn = H[n - 1];
+    if (H_IN_LDS) {                                         // only distances below m are needed here
+        double* hl = reinterpret_cast<double*>(smem_w);
+        for (int i = tid; i < m; i += 256) hl[i] = H[i];
+        H = hl;
+    }
+    __syncthreads();
+    if (tid < (1 << k)) {
+        int g = 0;
+        for (int c = 0; c < k; c++) if ((tid >> c) & 1) g += s_len[c];
+        s_glen[tid] = g;
+    }
+    __syncthreads();
+    double* __restrict__ base = tables + (int64_t)blockIdx.y * table_stride;
+    const int La = s_len[a], starta = we.w.start[a];
+    if (a == b) {
+        double acc = 0.0;
+        const int pairs = La * La;
+        for (int flat = tid; flat < pairs; flat += 256) {
+            const int e = flat / La, f = flat - e * La;
+            if (f > e) acc += M2[(int64_t)(starta + e) * ld2 + starta + f] * (hn - H[f - e - 1]);
+        }
+        acc = wave_sum_w(acc);
+        if (lane == 0) s_part[wave] = acc;
+        __syncthreads();
+        if (tid == 0) base[WT_SLICES * wt_q_size(k) + wt_p_size(k) + a] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        return;
+    }
+    const int Lb = s_len[b], startb = we.w.start[b];
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    double* __restrict__ P = base + WT_SLICES * wt_q_size(k) + ((((int64_t)a * k + b) * 4) << k);
+    const int n_sets = k >= 2 ? 1 << (k - 2) : 1, n_entries = 4 * n_sets, pairs = La * Lb;
+    for (int e0 = wave * WT_ACC; e0 < n_entries; e0 += 4 * WT_ACC) {
+        double acc[WT_ACC];
+        int gap[WT_ACC], ra[WT_ACC], rb[WT_ACC];
+#pragma unroll
+        for (int u = 0; u < WT_ACC; u++) {
+            const int e = e0 + u < n_entries ? e0 + u : n_entries - 1;
+            const int orient = e / n_sets, set = e - orient * n_sets;
+            ra[u] = orient >> 1; rb[u] = orient & 1;
+            gap[u] = s_glen[spread_bit(spread_bit(set, lo), hi)];
+            acc[u] = 0.0;
+        }
+#pragma unroll 2
+        for (int flat = lane; flat < pairs; flat += 64) {
+            const int ea = flat / Lb, eb = flat - ea * Lb;
+            const double v = M2[(int64_t)(starta + ea) * ld2 + startb + eb];
+#pragma unroll
+            for (int u = 0; u < WT_ACC; u++) {
+                const int i = ra[u] ? La - 1 - ea : ea, jj = rb[u] ? Lb - 1 - eb : eb;
+                const int d = La - i + gap[u] + jj;         // slot i of a ... gap ... slot jj of b
+                acc[u] += v * (hn - H[d - 1]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WT_ACC; u++) {
+            const double sum = wave_sum_w(acc[u]);
+            const int e = e0 + u;
+            if (lane == 0 && e < n_entries) {
+                const int orient = e / n_sets, set = e - orient * n_sets;
+                P[((int64_t)orient << k) | spread_bit(spread_bit(set, lo), hi)] = sum;
+            }
+        }
+    }
+}
+
+// ---- candidates: k + k(k-1)/2 look-ups each ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_win_candidates(int k, const int8_t* __restrict__ orders,
+                                                        const uint8_t* __restrict__ orients, int n_ori, int n_cand,
+                                                        const double* __restrict__ tables, int64_t table_stride,
+                                                        double* __restrict__ delta_all)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cand) return;
+    const double* __restrict__ base = tables + (int64_t)blockIdx.y * table_stride;
+    const double* __restrict__ Q = base;
+    const int64_t q_size = wt_q_size(k);
+    const double* __restrict__ P = base + WT_SLICES * q_size;
+    const double* __restrict__ C = P + wt_p_size(k);
+    const int8_t* __restrict__ ord = orders + (int64_t)(c / n_ori) * k;
+    const uint8_t* __restrict__ ori = orients + (int64_t)(c % n_ori) * k;
+    double sum = 0.0;
+    for (int j = 0; j < k; j++) sum += C[j];
+    int before = 0;
+    for (int s = 0; s < k; s++) {
+        const int a = ord[s], ra = ori[s] ? 1 : 0;
+        const int64_t qi = ((int64_t)(a * 2 + ra) << k) | before;
+#pragma unroll
+        for (int z = 0; z < WT_SLICES; z++) sum += Q[z * q_size + qi];
+        int between = 0;
+        for (int t = s + 1; t < k; t++) {
+            const int b = ord[t], rb = ori[t] ? 1 : 0;
+            sum += P[((((int64_t)a * k + b) * 4 + ra * 2 + rb) << k) | between];
+            between |= 1 << b;
+        }
+        before |= 1 << a;
+    }
+    delta_all[(int64_t)blockIdx.y * n_cand + c] = sum;
+}
+
+static std::atomic<int> g_lds_out{0}, g_lds_pairs{0};
+
+// tables: n_win * window_table_doubles(k) doubles of scratch; delta_all: n_win x (n_ord * n_ori)
+void launch_p2_window_tables(const double* M2, int64_t ld2, const int32_t* pos2sel, int n, int k,
+                             const WindowBatchEntry* wb, int n_win, int max_m, const int8_t* orders, const uint8_t* orients,
+                             int n_ord, int n_ori, const double* H, double* tables, double* delta_all, hipStream_t s)
+{
+    if (n_win <= 0 || k < 1) return;
+    const int64_t stride = window_table_doubles(k);
+    const size_t h_all = (((size_t)n * sizeof(double)) + 15) & ~(size_t)15;
+    const size_t h_win = (((size_t)max_m * sizeof(double)) + 15) & ~(size_t)15;
+    if (h_all <= 96 * 1024) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_win_outside<true>), g_lds_out, h_all);
+        hipLaunchKernelGGL(k_win_outside<true>, dim3(k, n_win, WT_SLICES), dim3(256), h_all, s, M2, ld2, pos2sel, n, k, wb, H, tables, stride);
+    } else {
+        hipLaunchKernelGGL(k_win_outside<false>, dim3(k, n_win, WT_SLICES), dim3(256), 0, s, M2, ld2, pos2sel, n, k, wb, H, tables, stride);
+    }
+    if (h_win <= 96 * 1024) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_win_pairs<true>), g_lds_pairs, h_win);
+        hipLaunchKernelGGL(k_win_pairs<true>, dim3(k * k, n_win), dim3(256), h_win, s, M2, ld2, n, k, wb, H, tables, stride);
+    } else {
+        hipLaunchKernelGGL(k_win_pairs<false>, dim3(k * k, n_win), dim3(256), 0, s, M2, ld2, n, k, wb, H, tables, stride);
+    }
+    const int n_cand = n_ord * n_ori;
+    hipLaunchKernelGGL(k_win_candidates, dim3((n_cand + 255) / 256, n_win), dim3(256), 0, s, k, orders, orients, n_ori, n_cand,
+                       tables, stride, delta_all);
+}
+
+}  // namespace hicmi

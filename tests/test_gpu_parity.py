@@ -400,13 +400,17 @@ def test_cli_drop_in(hic, tmp_path):
             assert fh.read() == gc.golden_text(name, fn), fn
 
 
-@pytest.mark.parametrize("env", [{"HICMI_P2_HOST_INSERT": "1"}, {"HICMI_P2_INS_MAXC": "1"}],
-                         ids=["host-decides-every-step", "device-with-host-steps-on-ties"])
+@pytest.mark.parametrize("env", [{"HICMI_P2_HOST_INSERT": "1"}, {"HICMI_P2_INS_MAXC": "1"}, {"HICMI_P2_WINDOW_DIRECT": "1"},
+                                 {"HICMI_PART2_LOCKSTEP": "0"}],
+                         ids=["host-decides-every-step", "device-with-host-steps-on-ties", "per-candidate-window-kernels",
+                              "one-queue-per-chromosome"])
 def test_insertion_paths_agree(hic, tmp_path, env):
     """orderRemainderScaffolds runs with the per-step decisions on the device (k_part2_insert.hip).  The same
     golden files must come out when the host decides every step, and when the device's short list is capped
-    at one candidate so that every tie falls back to a host step in the middle of the queue (the switches
-    are read once per process, hence the subprocess)."""
+    at one candidate so that every tie falls back to a host step in the middle of the queue; likewise with the
+    windows scored candidate by candidate instead of from placement tables (k_part2_window.hip) and with one
+    insertion queue per chromosome instead of the lock step (the switches are read once per process, hence the
+    subprocess)."""
     import subprocess
     import sys
     from hic_genome_assembler_amd import synth
