@@ -1,0 +1,68 @@
+"""Differential parity: the whole -part1 -part2 pipeline on the GPU against the CPU oracle on synthetic maps the
+golden fixtures do not cover - a few very large scaffolds (windows of hundreds of bins), mostly one-bin scaffolds
+(orientation ties, long insertion queues with host-decided steps), quantised sparse contacts (exact ties in the
+clustering, the rank order and the ordering scores) and other brute-force / scan window sizes.  Every output file
+must be identical (the oracle is pinned to the reference by tests/golden/, see oracle/hic_oracle.py)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # name, bins, chromosomes, mean scaffold bins, quantise, nScaffolds, scanScaffolds, psig
+    ("huge-scaffolds", 420, 3, 45.0, None, 6, 5, .05),
+    ("one-bin-scaffolds", 260, 3, 1.6, None, 6, 5, .05),
+    ("quantised-sparse", 360, 4, 7.0, (0.35, 2), 6, 5, .05),
+    ("small-windows", 300, 3, 9.0, None, 4, 3, .01),
+    ("k-equals-scan", 280, 2, 11.0, (0.2, 3), 5, 5, .05),
+]
+
+
+def _contacts(lay, seed, quantise):
+    from hic_genome_assembler_amd import synth
+    c = synth.dense_contacts(lay, seed=seed, sinkhorn_iters=8)
+    if quantise is not None:
+        frac, decimals = quantise
+        c = np.round(c, decimals)                           # equal values everywhere
+        cut = np.quantile(c, frac)
+        c[c <= cut] = 0.0                                   # ... and many exact zeros
+        c = 0.5 * (c + c.T)
+        np.fill_diagonal(c, np.maximum(np.diag(c), 1.0))    # no empty rows from the sparsification itself
+    return np.ascontiguousarray(c)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_pipeline_matches_oracle(case, tmp_path):
+    import hic_oracle as orc
+    from hic_genome_assembler_amd import orderGenome as p2, scaffoldToChromosomes as p1, synth
+    name, n, n_chrom, mean_scaf, quantise, n_scaffolds, scan_scaffolds, psig = case
+    seed = 100 + len(name)
+    lay = synth.make_layout(n, seed=seed, n_chrom=n_chrom, mean_scaffold_bins=mean_scaf)
+    c = _contacts(lay, seed, quantise)
+    paths = synth.write_hicpro(str(tmp_path / "in"), lay, c, "d")
+    outs = {}
+    for who in ("oracle", "gpu"):
+        out = tmp_path / who
+        out.mkdir()
+        f = lambda k: str(out / k)  # noqa: E731
+        if who == "oracle":
+            orc.run_part1(paths["hicProBedFile"], paths["hicProBiasFile"], paths["hicProMatrixFile"],
+                          paths["hicProScaffSizeFile"], f("dendrogramOrder.txt"), f("binGroups.txt"), f("assessment.txt"),
+                          f("chromosomeGroups.txt"), min_size=5, modularity=0.0, psig=psig)
+            orc.run_part2(paths["hicProBedFile"], paths["hicProBiasFile"], paths["hicProMatrixFile"],
+                          f("chromosomeGroups.txt"), f("chromosomeOrders.txt"), f("plotOrder.txt"),
+                          n_scaffolds=n_scaffolds, scan_scaffolds=scan_scaffolds)
+        else:
+            p1.runPipeline(paths["hicProBedFile"], paths["hicProBiasFile"], paths["hicProMatrixFile"],
+                           paths["hicProScaffSizeFile"], f("dendrogramOrder.txt"), False, False, f("binGroups.txt"),
+                           f("assessment.txt"), f("chromosomeGroups.txt"), True, False, 5, 0.0, 1, psig, 5, 5, lay.resolution)
+            p2.runPipeline(paths["hicProBedFile"], paths["hicProBiasFile"], paths["hicProMatrixFile"],
+                           f("chromosomeGroups.txt"), f("chromosomeOrders.txt"), False, False, False, "t", f("plotOrder.txt"),
+                           n_scaffolds, scan_scaffolds, lay.resolution)
+        outs[who] = {k: open(f(k)).read() for k in ("dendrogramOrder.txt", "binGroups.txt", "assessment.txt",
+                                                    "chromosomeGroups.txt", "chromosomeOrders.txt", "plotOrder.txt")}
+    for k in outs["oracle"]:
+        assert outs["gpu"][k] == outs["oracle"][k], (name, k)
+    assert len(outs["gpu"]["plotOrder.txt"]) > 0
