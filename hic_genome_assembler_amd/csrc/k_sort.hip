@@ -33,6 +33,7 @@ int sort_workgroups(int n)
 size_t sort_scratch_bytes(int n)
 {
     size_t P = (size_t)sort_padded_size(n);
+    if (P < 32) P = 32;
     return (size_t)sort_workgroups(n) * P * (sizeof(uint64_t) + sizeof(uint16_t));
 }
 
@@ -144,9 +145,183 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_rows(
     }
 }
 
+// ---- register-blocked network --------------------------------------------------------------------
+// The LDS version above moves every element through LDS at every one of the 105 stages of a 16384-element
+// sort.  Here a lane keeps RB_E = 16 CONSECUTIVE elements (key, column) in registers:
+//   strides 1..8      : compare-exchange inside the lane's registers, no memory at all
+//   strides 16..512   : the partner is 1..32 lanes away in the same wave -> wave shuffles, no barrier
+//   strides >= 1024   : the partner lane is in another wave -> the two lanes swap their blocks through
+//                       LDS (80 KB, two halves of 8 elements); 10 of the 105 stages
+// Rows longer than 16384 are sorted tile by tile and merged through the per-workgroup scratch as before.
+// Measured at 16k / 32k bins: 16.3 -> 12.3 ms / 75 -> 55 ms.  (32 elements x 512 lanes and 16 x 512 were
+// slower: 14.2 / 15.6 ms at 16k.)
+static constexpr int RB_E = 16;                        // elements per lane
+static constexpr int RB_T = 1024;                      // lanes per workgroup
+static constexpr int RB_TILE = RB_E * RB_T;            // 16384
+
+#define RB_LT(ka, ia, kb, ib) ((ka) < (kb) || ((ka) == (kb) && (ia) < (ib)))
+#define RB_CMPX(a, b, asc)                                                                    \
+    {                                                                                         \
+        const bool gt_ = RB_LT(K[b], I[b], K[a], I[a]);                                       \
+        if (gt_ == (asc)) { const uint64_t tk_ = K[a]; K[a] = K[b]; K[b] = tk_; const uint32_t ti_ = I[a]; I[a] = I[b]; I[b] = ti_; } \
+    }
+
+// stages j = min(j_max, RB_E/2) .. 1 of a level whose direction is the same for the whole lane
+__device__ __forceinline__ void rb_inreg_tail(uint64_t (&K)[RB_E], uint32_t (&I)[RB_E], bool asc, int j_max)
+{
+#pragma unroll
+    for (int j = RB_E / 2; j >= 1; j >>= 1) {
+        if (j <= j_max) {
+#pragma unroll
+            for (int q = 0; q < RB_E; q++)
+                if ((q & j) == 0) RB_CMPX(q, q | j, asc);
+        }
+    }
+}
+
+// partner lane = lane ^ m inside the wave; the lane with the clear bit keeps the minima when ascending
+__device__ __forceinline__ void rb_shuffle_stage(uint64_t (&K)[RB_E], uint32_t (&I)[RB_E], int m, bool keep_min)
+{
+#pragma unroll
+    for (int q = 0; q < RB_E; q++) {
+        const uint64_t ok = __shfl_xor(K[q], m, 64);
+        const uint32_t oi = __shfl_xor(I[q], m, 64);
+        const bool other_lt = RB_LT(ok, oi, K[q], I[q]);
+        if (other_lt == keep_min) { K[q] = ok; I[q] = oi; }
+    }
+}
+
+// partner lane = tid ^ m in another wave: both write their block, both read the other's
+__device__ __forceinline__ void rb_lds_stage(uint64_t (&K)[RB_E], uint32_t (&I)[RB_E], int tid, int m, bool keep_min,
+                                             uint64_t* xk, uint16_t* xi)
+{
+    constexpr int H = RB_E / 2;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int q = 0; q < H; q++) { xk[q * RB_T + tid] = K[h * H + q]; xi[q * RB_T + tid] = (uint16_t)I[h * H + q]; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            const uint64_t ok = xk[q * RB_T + (tid ^ m)];
+            const uint32_t oi = xi[q * RB_T + (tid ^ m)];
+            const bool other_lt = RB_LT(ok, oi, K[h * H + q], I[h * H + q]);
+            if (other_lt == keep_min) { K[h * H + q] = ok; I[h * H + q] = oi; }
+        }
+        __syncthreads();
+    }
+}
+
+// stages j = j_start .. 1 of level k on the tile held by the workgroup (j_start < tile, k >= 2 * RB_E)
+__device__ __forceinline__ void rb_tile_stages(uint64_t (&K)[RB_E], uint32_t (&I)[RB_E], int tid, int base, int k, int j_start,
+                                               uint64_t* xk, uint16_t* xi)
+{
+    const bool asc = ((base + RB_E * tid) & k) == 0;
+    for (int j = j_start; j >= RB_E; j >>= 1) {
+        const int m = j / RB_E;
+        const bool keep_min = ((tid & m) == 0) == asc;
+        if (m < 64) rb_shuffle_stage(K, I, m, keep_min);
+        else rb_lds_stage(K, I, tid, m, keep_min, xk, xi);
+    }
+    rb_inreg_tail(K, I, asc, j_start);
+}
+
+__global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
+    const double* __restrict__ C, int64_t ldc, const int32_t* __restrict__ order, const double* __restrict__ np_sum,
+    const double* __restrict__ seq_sum, int n, int P, uint64_t* __restrict__ skeys, uint16_t* __restrict__ sidx,
+    uint16_t* __restrict__ R, int64_t ldr)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* xk = reinterpret_cast<uint64_t*>(smem);                                   // (RB_E / 2) x RB_T keys
+    uint16_t* xi = reinterpret_cast<uint16_t*>(smem + (size_t)(RB_E / 2) * RB_T * sizeof(uint64_t));
+    const int tile = P < RB_TILE ? P : RB_TILE;            // P >= RB_E (launcher)
+    const int ntiles = P / tile;
+    const int tid = threadIdx.x;
+    const bool live = RB_E * tid < tile;                    // short rows use the first tile / RB_E lanes
+    uint64_t* gk = skeys + (size_t)blockIdx.x * (size_t)P;
+    uint16_t* gi = sidx + (size_t)blockIdx.x * (size_t)P;
+    uint64_t K[RB_E];
+    uint32_t I[RB_E];
+
+    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+        const int pa = order[row];
+        const double sig = np_sum[pa], rs = seq_sum[pa];
+        const double* __restrict__ crow = C + (int64_t)pa * ldc;
+        uint16_t* __restrict__ out = R + (int64_t)row * ldr;
+        for (int t = 0; t < ntiles; t++) {
+            const int base = t * tile;
+#pragma unroll
+            for (int q = 0; q < RB_E; q++) {
+                const int b = base + RB_E * tid + q;
+                K[q] = (live && b < n) ? key_of(similarity(crow[order[b]], sig, rs)) : ~0ull;
+                I[q] = (uint32_t)(b & 0xffff);
+            }
+            // levels 2 .. RB_E / 2: the direction alternates inside the lane (all indices are compile-time)
+#pragma unroll
+            for (int k = 2; k < RB_E; k <<= 1) {
+#pragma unroll
+                for (int j = k >> 1; j >= 1; j >>= 1) {
+#pragma unroll
+                    for (int q = 0; q < RB_E; q++)
+                        if ((q & j) == 0) RB_CMPX(q, q | j, (q & k) == 0);
+                }
+            }
+            rb_inreg_tail(K, I, ((base + RB_E * tid) & RB_E) == 0, RB_E / 2);                   // level RB_E: per lane
+            for (int k = 2 * RB_E; k <= tile; k <<= 1) rb_tile_stages(K, I, tid, base, k, k >> 1, xk, xi);
+            if (ntiles == 1) {
+                if (live) {
+#pragma unroll
+                    for (int q = 0; q < RB_E; q++) { const int e = RB_E * tid + q; if (e < n) out[n - 1 - e] = (uint16_t)I[q]; }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < RB_E; q++) { gk[base + RB_E * tid + q] = K[q]; gi[base + RB_E * tid + q] = (uint16_t)I[q]; }
+            }
+        }
+        // ---- merge levels above the tile size: strides >= tile in the scratch, the rest per tile in registers
+        for (int k = tile << 1; k <= P && ntiles > 1; k <<= 1) {
+            __syncthreads();
+            for (int j = k >> 1; j >= tile; j >>= 1) {
+                for (int p = tid; p < (P >> 1); p += RB_T) {
+                    int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                    cmpx(gk, gi, i, i + j, (i & k) == 0);
+                }
+                __syncthreads();
+            }
+            for (int t = 0; t < ntiles; t++) {
+                const int base = t * tile;
+#pragma unroll
+                for (int q = 0; q < RB_E; q++) { K[q] = gk[base + RB_E * tid + q]; I[q] = gi[base + RB_E * tid + q]; }
+                rb_tile_stages(K, I, tid, base, k, tile >> 1, xk, xi);
+                if (k == P) {
+#pragma unroll
+                    for (int q = 0; q < RB_E; q++) { const int e = base + RB_E * tid + q; if (e < n) out[n - 1 - e] = (uint16_t)I[q]; }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < RB_E; q++) { gk[base + RB_E * tid + q] = K[q]; gi[base + RB_E * tid + q] = (uint16_t)I[q]; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const double* np_sum, const double* seq_sum,
                       int n, void* scratch, uint16_t* R, int64_t ldr, hipStream_t s)
 {
+    static const bool lds_network = getenv("HICMI_SORT_LDS") != nullptr;      // A/B switch: the LDS-resident network
+    if (!lds_network) {
+        int P = sort_padded_size(n);
+        if (P < RB_E) P = RB_E;
+        const int wgs = sort_workgroups(n);
+        uint64_t* skeys = reinterpret_cast<uint64_t*>(scratch);
+        uint16_t* sidx = reinterpret_cast<uint16_t*>(skeys + (size_t)wgs * (size_t)P);
+        const size_t lds = (size_t)(RB_E / 2) * RB_T * (sizeof(uint64_t) + sizeof(uint16_t));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_rows_rb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_sort_rows_rb, dim3(wgs), dim3(RB_T), lds, s, C, ldc, order, np_sum, seq_sum, n, P, skeys,
+                           sidx, R, ldr);
+        return;
+    }
     const int P = sort_padded_size(n);
     const int tile = P < SORT_TILE ? P : SORT_TILE;
     const int wgs = sort_workgroups(n);
