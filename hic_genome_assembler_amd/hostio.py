@@ -2,10 +2,12 @@
 duplicated in orderGenome.py:19-93).
 
 The reference fills a Python list-of-lists cell by cell (~32 bytes per cell and minutes of
-interpreter time at N >= 16k).  Here the triplet file is parsed in chunks by pandas' C tokenizer
-with ``float_precision='round_trip'`` (the same correctly rounded conversion as Python's
-``float()``, which the reference applies at S2C:83) straight into one dense fp64 array that is
-then uploaded to HBM once.
+interpreter time at N >= 16k).  Here the triplet file goes straight into one dense fp64 array that is
+uploaded to HBM once: by libhicmi's multi-threaded mmap parser (csrc/loader.hip, the default), or by
+pandas' C tokenizer with ``float_precision='round_trip'`` (an independent second implementation) - both
+apply the correctly rounded conversion of Python's ``float()``, which the reference uses at S2C:83.
+``read_contact_matrix_cached`` adds a binary cache of the parsed matrix; ``paused_gc`` is the helper the
+host stages run under.
 """
 from __future__ import annotations
 
