@@ -157,7 +157,7 @@ def main():
         traffic, traffic_src = None, None
         pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_part1_16k.json")))
         pmc_file = pmc_files[-1] if pmc_files else ""             # the latest committed collection
-        pmc_kernel = {"nnchain": "hicmi::k_nn_epoch<false>", "sort_rows": "hicmi::k_sort_rows"}.get(fam)
+        pmc_kernel = {"nnchain": "hicmi::k_nn_epoch<false>", "sort_rows": "hicmi::k_sort_rows_rb"}.get(fam)
         if n == 16000 and pmc_kernel and os.path.exists(pmc_file):
             with open(pmc_file) as fh:
                 pmc = json.load(fh)
