@@ -19,6 +19,15 @@ CASES = [
     ("k-equals-scan", 280, 2, 11.0, (0.2, 3), 5, 5, .05),
 ]
 
+# Part 2 alone on the planted chromosomes (the cut scan over-segments maps this small, which would leave no
+# chromosome with more scaffolds than the windows are wide)
+P2_CASES = [
+    # name, bins, chromosomes, mean scaffold bins, quantise, nScaffolds, scanScaffolds
+    ("two-scaffold-windows", 180, 2, 6.0, None, 3, 2),
+    ("six-scaffold-scan-windows", 150, 1, 9.0, None, 6, 6),
+    ("seven-scaffold-brute-force", 120, 1, 12.0, (0.2, 2), 7, 4),
+]
+
 
 def _contacts(lay, seed, quantise):
     from hic_genome_assembler_amd import synth
@@ -66,3 +75,34 @@ def test_pipeline_matches_oracle(case, tmp_path):
     for k in outs["oracle"]:
         assert outs["gpu"][k] == outs["oracle"][k], (name, k)
     assert len(outs["gpu"]["plotOrder.txt"]) > 0
+
+
+@pytest.mark.parametrize("case", P2_CASES, ids=[c[0] for c in P2_CASES])
+def test_part2_matches_oracle_on_planted_groups(case, tmp_path):
+    import hic_oracle as orc
+    from hic_genome_assembler_amd import orderGenome as p2, synth
+    name, n, n_chrom, mean_scaf, quantise, n_scaffolds, scan_scaffolds = case
+    seed = 200 + len(name)
+    lay = synth.make_layout(n, seed=seed, n_chrom=n_chrom, mean_scaffold_bins=mean_scaf)
+    c = _contacts(lay, seed, quantise)
+    paths = synth.write_hicpro(str(tmp_path / "in"), lay, c, "d")
+    groups = tmp_path / "chromosomeGroups.txt"
+    with open(groups, "w") as fh:
+        for g in range(n_chrom):
+            fh.write("### Chromosome group %d ###\n" % (g + 1))
+            for k in np.flatnonzero(lay.chrom_of_bin == g):
+                fh.write("%d\t%s\n" % (lay.bin_ids[k], lay.scaffold_names[lay.scaffold_of_bin[k]]))
+    outs = {}
+    for who in ("oracle", "gpu"):
+        out = tmp_path / who
+        out.mkdir()
+        f = lambda k: str(out / k)  # noqa: E731
+        if who == "oracle":
+            orc.run_part2(paths["hicProBedFile"], paths["hicProBiasFile"], paths["hicProMatrixFile"], str(groups),
+                          f("chromosomeOrders.txt"), f("plotOrder.txt"), n_scaffolds=n_scaffolds, scan_scaffolds=scan_scaffolds)
+        else:
+            p2.runPipeline(paths["hicProBedFile"], paths["hicProBiasFile"], paths["hicProMatrixFile"], str(groups),
+                           f("chromosomeOrders.txt"), False, False, False, "t", f("plotOrder.txt"), n_scaffolds,
+                           scan_scaffolds, lay.resolution)
+        outs[who] = {k: open(f(k)).read() for k in ("chromosomeOrders.txt", "plotOrder.txt")}
+    assert outs["gpu"] == outs["oracle"], name
