@@ -139,6 +139,7 @@ class Context:
         self.n = 0
         self._keepalive = None
         self._workers = []
+        self._n_window_cand = 0
 
     def close(self):
         for w in getattr(self, "_workers", []):
@@ -316,6 +317,8 @@ class Context:
         self._n_window_cand = a.shape[0] * b.shape[0]
 
     def p2_score_window(self, first: int, k: int):
+        if not self._n_window_cand:
+            raise HicmiError("p2_window_tables has not been called")
         out = np.empty(self._n_window_cand, np.float64)
         _check(self._lib.hicmi_p2_score_window(self._h, int(first), int(k), _ptr(out)))
         return out

@@ -604,3 +604,42 @@ def test_louvain_tail_same_on_gpu_and_oracle(hic, tmp_path, monkeypatch):
         texts[run] = [open(f(k)).read() for k in ("binGroups.txt", "assessment.txt", "chromosomeGroups.txt")]
     assert texts["gpu"] == texts["oracle"]
     assert texts["gpu"][0].count("### Chromosome group") >= 2
+
+
+def test_api_misuse_is_reported_not_executed(hic):
+    """Calls in the wrong order or with operands that do not match the resident matrix must come back as
+    HicmiError (a negative HICMI_E* code and a message) - never as a kernel launched on bad shapes."""
+    spec, meta, gold, lay, c = gc.load_case("n160")
+    n = len(c)
+    with hic.Context(0) as ctx:
+        with pytest.raises(hic.HicmiError):
+            ctx.upgma()                                              # no contact matrix yet
+        with pytest.raises(hic.HicmiError):
+            ctx.plot_downsample(0, None, 4)
+        ctx.set_contacts(c)
+        with pytest.raises((hic.HicmiError, ValueError)):
+            ctx.rank_matrix(list(range(n - 1)))                      # order of the wrong length
+        with pytest.raises(hic.HicmiError):
+            ctx.cut_scan(0, n, .05)                                  # rank matrix not built
+        with pytest.raises(hic.HicmiError):
+            ctx.plot_downsample(0, None, n + 1)                      # more pixels than cells
+        with pytest.raises(hic.HicmiError):
+            ctx.plot_percentiles(3, None, [50])                      # unknown transform
+        with pytest.raises(hic.HicmiError):
+            ctx.plot_percentiles(0, [n], [50])                       # row outside the matrix
+        with pytest.raises(hic.HicmiError):
+            ctx.p2_total()                                           # nothing selected
+        ctx.p2_select(list(range(20)))
+        with pytest.raises(hic.HicmiError):
+            ctx.p2_set_arrangement([0], [0])                         # no layout
+        ctx.p2_layout([0, 10], [10, 10])
+        with pytest.raises(hic.HicmiError):
+            ctx.p2_set_arrangement([0, 0], [0, 0])                   # a scaffold twice
+        ctx.p2_set_arrangement([0, 1], [0, 1])
+        with pytest.raises(hic.HicmiError):
+            ctx.p2_score_window(0, 2)                                # window tables not loaded
+        with pytest.raises(hic.HicmiError):
+            ctx.p2_insert_all([0, 1], [0, 0], [1])                   # scaffold already placed
+        # the context is still usable afterwards
+        leaves, z = ctx.upgma()
+        assert sorted(leaves.tolist()) == list(range(n))
