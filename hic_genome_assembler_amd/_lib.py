@@ -62,6 +62,9 @@ SIGNATURES = {
                                                  ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_int32),
                                                  ctypes.POINTER(c_dbl)]),
     "hicmi_p2_insert_all": (ctypes.c_int, [_vp, _vp, _vp, c_i64, _vp, c_i64, ctypes.POINTER(c_dbl)]),
+    "hicmi_scan_valid_pairs": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _vp, c_i64, _vp, _vp, c_i64, ctypes.c_int,
+                                              ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(_vp)]),
+    "hicmi_scan_fetch": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "hicmi_plot_percentiles": (ctypes.c_int, [_vp, ctypes.c_int, _vp, c_i64, _vp, c_i64, _vp]),
     "hicmi_plot_downsample": (ctypes.c_int, [_vp, ctypes.c_int, _vp, c_i64, c_i64, _vp]),
     "hicmi_p2_insert_all_multi": (ctypes.c_int, [c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -120,6 +123,26 @@ def load_hicpro_matrix(path, bin_ids, threads: int = 0):
     edges = c_i64()
     _check(load().hicmi_load_hicpro_matrix(os.fsencode(path), _ptr(ids), n, _ptr(out), int(threads), ctypes.byref(edges)))
     return out, edges.value
+
+
+def scan_valid_pairs(path, names, pairs, threads: int = 0):
+    """Lines of a HiC-Pro allValidPairs file that name one of the ordered scaffold pairs ``pairs`` (indices
+    into ``names``): returns (pair index, pos1, pos2) arrays in file order and the number of lines read."""
+    enc = [n.encode("utf-8") for n in names]
+    blob = b"".join(enc)
+    off = np.zeros(len(enc) + 1, np.int64)
+    if enc:
+        off[1:] = np.cumsum([len(e) for e in enc])
+    pa = np.ascontiguousarray([p[0] for p in pairs], dtype=np.int32)
+    pb = np.ascontiguousarray([p[1] for p in pairs], dtype=np.int32)
+    n_hits, n_lines, handle = c_i64(), c_i64(), _vp()
+    _check(load().hicmi_scan_valid_pairs(os.fsencode(path), blob, _ptr(off), len(enc), _ptr(pa), _ptr(pb), len(pa), int(threads),
+                                         ctypes.byref(n_hits), ctypes.byref(n_lines), ctypes.byref(handle)))
+    idx = np.empty(n_hits.value, np.int32)
+    p1 = np.empty(n_hits.value, np.int64)
+    p2 = np.empty(n_hits.value, np.int64)
+    _check(load().hicmi_scan_fetch(handle, _ptr(idx), _ptr(p1), _ptr(p2)))
+    return idx, p1, p2, n_lines.value
 
 
 def hypergeom_sf(x, M, n, N) -> float:

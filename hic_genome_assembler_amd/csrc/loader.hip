@@ -227,3 +227,134 @@ extern "C" int hicmi_load_hicpro_matrix(const char* path, const int64_t* bin_ids
     if (edges_out) *edges_out = total;
     return HICMI_OK;
 }
+
+// ---- valid-pair scan (orientSmallScaffolds.py:159-177 readValidPairFile) ---------
+// HiC-Pro allValidPairs lines: read <TAB> scaffold1 <TAB> pos1 <TAB> strand1 <TAB> scaffold2 <TAB> pos2 ...
+// The reference keeps, for every ORDERED pair of neighbouring scaffold names it registered, the two positions of
+// each line naming that pair; everything else in a multi-GB file is skipped.  Same host-side scheme as the
+// matrix loader: mmap, per-thread chunks cut at line starts, hits collected per thread and concatenated in
+// thread order = file order.
+#include <unordered_map>
+#include <string_view>
+
+namespace {
+struct PairHit { int32_t pair; int64_t p1, p2; };
+struct ScanResult { std::vector<PairHit> hits; };
+
+inline bool parse_pos(const char* p, const char* end, int64_t& out)
+{
+    // Python int(): optional sign, digits, surrounding blanks tolerated
+    while (p < end && (*p == ' ')) p++;
+    while (end > p && (end[-1] == ' ')) end--;
+    bool ok = true;
+    const char* q = parse_i64(p, end, out, ok);
+    return ok && q == end;
+}
+}  // namespace
+
+extern "C" int hicmi_scan_valid_pairs(const char* path, const char* names_blob, const int64_t* name_off, int64_t n_names,
+                                      const int32_t* pair_a, const int32_t* pair_b, int64_t n_pairs, int threads,
+                                      int64_t* n_hits_out, int64_t* n_lines_out, void** handle_out)
+{
+    auto err = [](int code, const std::string& msg) { return hicmi::set_error(code, msg.c_str()); };
+    if (!path || !names_blob || !name_off || !n_hits_out || !n_lines_out || !handle_out || n_names < 0 || n_pairs < 0 ||
+        (n_pairs > 0 && (!pair_a || !pair_b)))
+        return err(HICMI_EINVAL, "bad arguments");
+    *n_hits_out = 0; *n_lines_out = 0; *handle_out = nullptr;
+    std::unordered_map<std::string_view, int32_t> name_id;
+    name_id.reserve((size_t)n_names * 2);
+    for (int64_t i = 0; i < n_names; i++)
+        name_id.emplace(std::string_view(names_blob + name_off[i], (size_t)(name_off[i + 1] - name_off[i])), (int32_t)i);
+    std::unordered_map<uint64_t, int32_t> pair_id;
+    pair_id.reserve((size_t)n_pairs * 2);
+    for (int64_t i = 0; i < n_pairs; i++) {
+        if (pair_a[i] < 0 || pair_a[i] >= n_names || pair_b[i] < 0 || pair_b[i] >= n_names) return err(HICMI_EINVAL, "pair names out of range");
+        pair_id[((uint64_t)(uint32_t)pair_a[i] << 32) | (uint32_t)pair_b[i]] = (int32_t)i;
+    }
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return err(HICMI_EINVAL, std::string("cannot open ") + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return err(HICMI_EINVAL, "fstat failed"); }
+    const size_t size = (size_t)st.st_size;
+    auto* res = new ScanResult();
+    if (size == 0) { close(fd); *handle_out = res; return HICMI_OK; }
+    const char* data = (const char*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (data == MAP_FAILED) { delete res; return err(HICMI_ENOMEM, "mmap failed"); }
+    madvise((void*)data, size, MADV_SEQUENTIAL);
+    int T = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    T = std::max(1, std::min(T, 64));
+    if (size < (size_t)T * 4096) T = 1;
+    std::vector<size_t> cut((size_t)T + 1, size);
+    cut[0] = 0;
+    for (int t = 1; t < T; t++) {
+        size_t p = size / (size_t)T * (size_t)t;
+        while (p < size && data[p] != '\n') p++;
+        cut[(size_t)t] = p < size ? p + 1 : size;
+    }
+    std::vector<std::vector<PairHit>> part((size_t)T);
+    std::vector<int64_t> lines((size_t)T, 0), bad((size_t)T, -1);
+    auto work = [&](int t) {
+        const char* p = data + cut[(size_t)t];
+        const char* end = data + cut[(size_t)t + 1];
+        auto& out = part[(size_t)t];
+        while (p < end) {
+            const char* eol = (const char*)memchr(p, '\n', (size_t)(end - p));
+            if (!eol) eol = end;
+            const char* le = eol;
+            while (le > p && le[-1] == '\r') le--;
+            // columns 0..5
+            const char* col[7];
+            int nc = 0;
+            col[nc++] = p;
+            for (const char* q = p; nc < 7;) {
+                const char* tab = (const char*)memchr(q, '\t', (size_t)(le - q));
+                if (!tab) break;
+                col[nc++] = tab + 1;
+                q = tab + 1;
+            }
+            if (nc < 6) { bad[(size_t)t] = (int64_t)(p - data); return; }   // cols[4] / cols[5] missing: IndexError in the reference
+            const char* c5_end = nc >= 7 ? col[6] - 1 : le;
+            lines[(size_t)t]++;
+            auto a = name_id.find(std::string_view(col[1], (size_t)(col[2] - 1 - col[1])));
+            if (a != name_id.end()) {
+                auto b = name_id.find(std::string_view(col[4], (size_t)(col[5] - 1 - col[4])));
+                if (b != name_id.end()) {
+                    auto hit = pair_id.find(((uint64_t)(uint32_t)a->second << 32) | (uint32_t)b->second);
+                    if (hit != pair_id.end()) {
+                        int64_t p1 = 0, p2 = 0;
+                        if (!parse_pos(col[2], col[3] - 1, p1) || !parse_pos(col[5], c5_end, p2)) { bad[(size_t)t] = (int64_t)(p - data); return; }
+                        out.push_back({hit->second, p1, p2});
+                    }
+                }
+            }
+            p = eol + 1;
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; t++) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
+    munmap((void*)data, size);
+    for (int t = 0; t < T; t++)
+        if (bad[(size_t)t] >= 0) { delete res; return err(HICMI_EINVAL, "malformed valid-pair line at byte " + std::to_string(bad[(size_t)t])); }
+    size_t total = 0;
+    for (auto& v : part) total += v.size();
+    res->hits.reserve(total);
+    for (auto& v : part) res->hits.insert(res->hits.end(), v.begin(), v.end());
+    int64_t n_lines = 0;
+    for (auto v : lines) n_lines += v;
+    *n_hits_out = (int64_t)total; *n_lines_out = n_lines; *handle_out = res;
+    return HICMI_OK;
+}
+
+extern "C" int hicmi_scan_fetch(void* handle, int32_t* pair_idx, int64_t* pos1, int64_t* pos2)
+{
+    if (!handle) return hicmi::set_error(HICMI_EINVAL, "NULL handle");
+    auto* res = reinterpret_cast<ScanResult*>(handle);
+    if (!res->hits.empty() && (!pair_idx || !pos1 || !pos2)) return hicmi::set_error(HICMI_EINVAL, "NULL output");
+    for (size_t i = 0; i < res->hits.size(); i++) { pair_idx[i] = res->hits[i].pair; pos1[i] = res->hits[i].p1; pos2[i] = res->hits[i].p2; }
+    delete res;
+    return HICMI_OK;
+}

@@ -171,9 +171,13 @@ def main(argv=None):
                           v["chromosomeOrderFile"], v["savePlotsDirectory"], v["chromosomePlotSuffix"],
                           v["fullGenomePlot"], v["fullGenomePlotTitle"], v["plotOrderFile"],
                           v["nScaffolds"], v["scanScaffolds"], v["resolution"], device=args.device)
-    if args.part3 or args.part4:
-        print("Parts 3 and 4 are not part of the MI355X-accelerated path; run them with the reference implementation.")
-        sys.exit(3)
+    if args.part3:
+        from . import orientSmallScaffolds as part3
+        part3.runPipeline(v["chromosomeOrderFile"], v["hicProScaffSizeFile"], v["restrictionSiteFile"], v["validPairFile"],
+                          v["finalOrderingsFile"], v["lengthCutoff"], v["resolution"])
+    if args.part4:
+        from . import writeAssembledFasta as part4
+        part4.runPipeline(v["originalFastaFile"], v["finalOrderingsFile"], v["assembledFastaFile"])
     print("Total run-time = " + str(time.time() - t0) + " seconds")
 
 

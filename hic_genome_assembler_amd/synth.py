@@ -250,3 +250,83 @@ def write_config(path: str, hicpro_paths: dict, save_dir: str, plot_dir: str, re
     with open(path, "w") as fh:
         fh.write("\n".join(lines) + "\n")
     return path
+
+
+# ---- inputs of Parts 3 and 4 (orientSmallScaffolds.py, writeAssembledFasta.py) ---------------------------------
+def write_part34_inputs(out_dir: str, order_file: str, size_file: str, seed: int = 1, pairs_per_join: int = 400,
+                        noise_pairs: int = 5000, site_spacing: int = 4000, fasta_scale: int = 100,
+                        prefix: str = "synth") -> dict:
+    """Restriction-site, valid-pair and FASTA files for a chromosome-order file written by Part 2.
+
+    * restriction sites (HiC-Pro digest BED: ``scaffold start end name 0 +``): one about every
+      ``site_spacing`` bp; the reference reads columns 0 and 2 (orientSmallScaffolds.py:74-83);
+    * valid pairs (HiC-Pro allValidPairs: ``read scaf1 pos1 strand1 scaf2 pos2 strand2 ...``): for every pair of
+      neighbouring scaffolds ``pairs_per_join`` read pairs drawn near the two facing ends (either mate first),
+      plus ``noise_pairs`` between random scaffolds that the scan has to skip; columns 1, 2, 4, 5 are used
+      (orientSmallScaffolds.py:159-177);
+    * FASTA: random ACGT (some N, some lower case) of ``size / fasta_scale`` bases per scaffold, 60 per line,
+      plus two scaffolds that are in no chromosome group.
+    Returns the three paths keyed by the reference's config names.
+    """
+    rng = np.random.default_rng(seed)
+    os.makedirs(out_dir, exist_ok=True)
+    sizes = {}
+    with open(size_file) as fh:
+        for line in fh:
+            name, size = line.rstrip("\r\n").split("\t")[:2]
+            sizes[name] = int(size)
+    groups, cur = [], []
+    with open(order_file) as fh:
+        fh.readline()
+        for line in fh:
+            line = line.rstrip("\r\n")
+            if line.startswith("#"):
+                groups.append(cur)
+                cur = []
+            else:
+                cur.append(line.split("\t")[:2])
+    groups.append(cur)
+    paths = {"restrictionSiteFile": os.path.join(out_dir, prefix + "_restriction.bed"),
+             "validPairFile": os.path.join(out_dir, prefix + ".allValidPairs"),
+             "originalFastaFile": os.path.join(out_dir, prefix + ".fasta")}
+    names = list(sizes)
+    with open(paths["restrictionSiteFile"], "w") as fh:
+        for name in names:
+            pos, k = 0, 0
+            while True:
+                pos += int(rng.integers(site_spacing // 2, site_spacing * 3 // 2))
+                if pos >= sizes[name]:
+                    break
+                fh.write("%s\t%d\t%d\tHIC_%s_%d\t0\t+\n" % (name, max(pos - 4, 0), pos, name, k))
+                k += 1
+    lines = []
+    rid = 0
+    for grp in groups:
+        for (a, oa), (b, ob) in zip(grp, grp[1:]):
+            for _ in range(pairs_per_join):
+                # a's end that faces b, b's end that faces a (exponential fall-off into the scaffolds)
+                da = min(int(rng.exponential(60000.0)), sizes[a] - 1)
+                db = min(int(rng.exponential(60000.0)), sizes[b] - 1)
+                pa = sizes[a] - 1 - da if oa == "+" else da
+                pb = db if ob == "+" else sizes[b] - 1 - db
+                if rng.random() < 0.5:
+                    lines.append("read%d\t%s\t%d\t+\t%s\t%d\t-\t300\tf1\tf2\t42\t42" % (rid, a, pa + 1, b, pb + 1))
+                else:
+                    lines.append("read%d\t%s\t%d\t-\t%s\t%d\t+\t300\tf1\tf2\t42\t42" % (rid, b, pb + 1, a, pa + 1))
+                rid += 1
+    for _ in range(noise_pairs):
+        a, b = names[int(rng.integers(len(names)))], names[int(rng.integers(len(names)))]
+        lines.append("read%d\t%s\t%d\t+\t%s\t%d\t-\t300\tf1\tf2\t42\t42"
+                     % (rid, a, int(rng.integers(1, sizes[a] + 1)), b, int(rng.integers(1, sizes[b] + 1))))
+        rid += 1
+    order = rng.permutation(len(lines))
+    with open(paths["validPairFile"], "w") as fh:
+        fh.write("".join(lines[i] + "\n" for i in order))
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNn", dtype=np.uint8)
+    with open(paths["originalFastaFile"], "w") as fh:
+        for name in names + ["unplaced_1", "unplaced_2"]:
+            n_bases = max(1, sizes.get(name, 1234 * fasta_scale) // fasta_scale)
+            seq = alphabet[rng.integers(0, len(alphabet), size=n_bases)].tobytes().decode("ascii")
+            fh.write(">" + name + "\n")
+            fh.write("".join(seq[i:i + 60] + "\n" for i in range(0, len(seq), 60)))
+    return paths

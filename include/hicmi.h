@@ -216,6 +216,19 @@ int hicmi_p2_scan_pass(hicmi_ctx *ctx, int32_t *ids, uint8_t *rev, int64_t S, in
 int hicmi_p2_insert_all_multi(int64_t n_jobs, hicmi_ctx *const *ctxs, int32_t *const *ids, uint8_t *const *rev,
                               const int64_t *S0, const int32_t *const *new_ids, const int64_t *n_new, double *best_out);
 
+/* ---- Part 3 input scan (host code, no GPU) -----------------------------------------------------
+ * readValidPairFile (orientSmallScaffolds.py:159-177): of a HiC-Pro allValidPairs file
+ * (read, scaffold1, pos1, strand1, scaffold2, pos2, ...) keep the lines whose (scaffold1, scaffold2) is one of the
+ * registered ORDERED name pairs.  names_blob / name_off[n_names + 1]: the scaffold names, concatenated;
+ * pair_a / pair_b: name indices of the n_pairs registered pairs.  hicmi_scan_valid_pairs parses the file with
+ * `threads` host threads (0 = all) and returns the number of hits and of lines; hicmi_scan_fetch copies the hits
+ * out in file order - (registered pair, pos1, pos2) - and releases the handle.  A line with fewer than six
+ * columns or a non-integer position of a registered pair is an error, as in the reference. */
+int hicmi_scan_valid_pairs(const char *path, const char *names_blob, const int64_t *name_off, int64_t n_names,
+                           const int32_t *pair_a, const int32_t *pair_b, int64_t n_pairs, int threads,
+                           int64_t *n_hits_out, int64_t *n_lines_out, void **handle_out);
+int hicmi_scan_fetch(void *handle, int32_t *pair_idx, int64_t *pos1, int64_t *pos2);
+
 /* ---- plot support -----------------------------------------------------------------------------
  * plotContactMap (plotContactMaps.py:15-91) colours every cell of an N x N matrix between two
  * numpy.percentile limits.  The matrix stays on the device: kind 0 = raw contacts (Part 2 plots,
