@@ -1,9 +1,9 @@
-"""Command-line driver: ``run_hicAssembler.py [-part1] [-part2] -config FILE`` - same flags, same
-``key = value`` config format and same file layout as the reference driver
+"""Command-line driver: ``run_hicAssembler.py [-part1] [-part2] [-part3] [-part4] -config FILE`` - same flags,
+same ``key = value`` config format and same file layout as the reference driver
 (/root/reference/HIC_ASSEMBLER/run_hicAssembler.py, RUN below), with Parts 1 and 2 executed on
-MI355X.  Parts 3 and 4 (read-pair orientation of small scaffolds, FASTA writing) are outside the
-accelerated path; asking for them reports that and exits non-zero
-after the accelerated parts have run.
+MI355X.  Parts 3 and 4 (read-pair orientation of small scaffolds, FASTA writing) are host-side text
+stages (orientSmallScaffolds.py with libhicmi's multi-threaded valid-pair scanner,
+writeAssembledFasta.py).
 
 Config rules kept from the reference parser (RUN:9-245):
  * lines are ``name = value`` split on the literal `` = ``; blank lines and lines starting with '#'
