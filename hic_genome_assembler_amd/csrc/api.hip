@@ -188,10 +188,8 @@ int upload(hicmi_ctx* c, void* dst, const void* src, size_t bytes)
     return HICMI_OK;
 }
 
-// device -> pageable host through the pinned download buffer; synchronises the stream
-int download(hicmi_ctx* c, void* dst, const void* src, size_t bytes)
+int ensure_pin_down(hicmi_ctx* c, size_t bytes)
 {
-    if (bytes == 0) { HIPCHK(sync_stream(c)); return HICMI_OK; }
     if (bytes > c->pin_down_cap) {
         if (c->pin_down) (void)hipHostFree(c->pin_down);
         c->pin_down = nullptr; c->pin_down_cap = 0;
@@ -199,6 +197,15 @@ int download(hicmi_ctx* c, void* dst, const void* src, size_t bytes)
         HIPCHK(hipHostMalloc((void**)&c->pin_down, cap, hipHostMallocDefault));
         c->pin_down_cap = cap;
     }
+    return HICMI_OK;
+}
+
+// device -> pageable host through the pinned download buffer; synchronises the stream
+int download(hicmi_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) { HIPCHK(sync_stream(c)); return HICMI_OK; }
+    int rc_pin = ensure_pin_down(c, bytes);
+    if (rc_pin) return rc_pin;
     HIPCHK(hipMemcpyAsync(c->pin_down, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(sync_stream(c));
     memcpy(dst, c->pin_down, bytes);
@@ -616,6 +623,30 @@ static int ensure_scan_buffers(hicmi_ctx* c)
     return HICMI_OK;
 }
 
+// The significance flags of the rows counted in d_x.  The flags are all the host loops need, tens of thousands of
+// times per map: the kernel writes them straight into the pinned buffer (no copy kernel, one synchronisation).
+static int finish_scan(hicmi_ctx* c, int64_t rows, int mode, int64_t L_fixed, int64_t M, double psig, int32_t* x_out,
+                       uint8_t* sig_out)
+{
+    const bool direct = sig_out && !x_out;
+    if (direct) { int rc = ensure_pin_down(c, (size_t)rows); if (rc) return rc; }
+    {
+        Timed t(c, F_HYPER_FLAGS, 5.0 * (double)rows);
+        launch_hyper_flags(c->d_x, (int)rows, mode, (int)L_fixed, M, psig, direct ? reinterpret_cast<uint8_t*>(c->pin_down) : c->d_sig,
+                           c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    if (direct) {
+        HIPCHK(sync_stream(c));
+        memcpy(sig_out, c->pin_down, (size_t)rows);
+        return HICMI_OK;
+    }
+    if (x_out) { int rc = download(c, x_out, c->d_x, sizeof(int32_t) * (size_t)rows); if (rc) return rc; }
+    if (sig_out) { int rc = download(c, sig_out, c->d_sig, (size_t)rows); if (rc) return rc; }
+    if (!x_out && !sig_out) HIPCHK(sync_stream(c));
+    return HICMI_OK;
+}
+
 int hicmi_cut_scan(hicmi_ctx* c, int64_t start, int64_t M, double psig, int32_t* x_out, uint8_t* sig_out)
 {
     if (!c) return fail(HICMI_EINVAL, "NULL context");
@@ -634,15 +665,7 @@ int hicmi_cut_scan(hicmi_ctx* c, int64_t start, int64_t M, double psig, int32_t*
         HIPCHK(hipGetLastError());
         c->cached_start = start;
     }
-    {
-        Timed t(c, F_HYPER_FLAGS, 5.0 * (double)cnt);
-        launch_hyper_flags(c->d_x, (int)cnt, 0, 0, M, psig, c->d_sig, c->stream);
-    }
-    HIPCHK(hipGetLastError());
-    if (x_out) HIPCHK(hipMemcpyAsync(x_out, c->d_x, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
-    if (sig_out) HIPCHK(hipMemcpyAsync(sig_out, c->d_sig, (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(sync_stream(c));
-    return HICMI_OK;
+    return finish_scan(c, cnt, 0, 0, M, psig, x_out, sig_out);
 }
 
 int hicmi_filter_scan(hicmi_ctx* c, int64_t start, int64_t cut, int64_t n_rows, int64_t M, double psig,
@@ -662,15 +685,7 @@ int hicmi_filter_scan(hicmi_ctx* c, int64_t start, int64_t cut, int64_t n_rows, 
         launch_cut_count(c->dRank, c->ldr, (int)start, (int)n_rows, (int)start, 1, (int)cut, c->d_x, c->stream);
     }
     HIPCHK(hipGetLastError());
-    {
-        Timed t(c, F_HYPER_FLAGS, 5.0 * (double)n_rows);
-        launch_hyper_flags(c->d_x, (int)n_rows, 1, (int)(cut - start), M, psig, c->d_sig, c->stream);
-    }
-    HIPCHK(hipGetLastError());
-    if (x_out) HIPCHK(hipMemcpyAsync(x_out, c->d_x, sizeof(int32_t) * (size_t)n_rows, hipMemcpyDeviceToHost, c->stream));
-    if (sig_out) HIPCHK(hipMemcpyAsync(sig_out, c->d_sig, (size_t)n_rows, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(sync_stream(c));
-    return HICMI_OK;
+    return finish_scan(c, n_rows, 1, cut - start, M, psig, x_out, sig_out);
 }
 
 double hicmi_hypergeom_sf(int64_t x, int64_t M, int64_t n, int64_t N) { return hypergeom_sf_ge(x, M, n, N); }
