@@ -368,9 +368,9 @@ int hicmi_row_sums(hicmi_ctx* c, double* np_sum, double* seq_sum)
     HIPCHK(hipSetDevice(c->device));
     int rc = compute_sums(c);
     if (rc) return rc;
-    if (np_sum) HIPCHK(hipMemcpyAsync(np_sum, c->d_np, sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
-    if (seq_sum) HIPCHK(hipMemcpyAsync(seq_sum, c->d_seq, sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(sync_stream(c));
+    if (np_sum) { rc = download(c, np_sum, c->d_np, sizeof(double) * (size_t)c->n); if (rc) return rc; }
+    if (seq_sum) { rc = download(c, seq_sum, c->d_seq, sizeof(double) * (size_t)c->n); if (rc) return rc; }
+    if (!np_sum && !seq_sum) HIPCHK(sync_stream(c));
     return HICMI_OK;
 }
 
@@ -511,9 +511,12 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
     int status = 0;
     c->zraw.assign((size_t)(4 * (n - 1)), 0.0);
     int nn_state[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(nn_state, nnchain_state_ptr(c->d_size), sizeof(nn_state), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->zraw.data(), c->d_zraw, sizeof(double) * 4 * (size_t)(n - 1), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(sync_stream(c));
+    {
+        int rc_dl = download(c, nn_state, nnchain_state_ptr(c->d_size), sizeof(nn_state));
+        if (rc_dl) return rc_dl;
+        rc_dl = download(c, c->zraw.data(), c->d_zraw, sizeof(double) * 4 * (size_t)(n - 1));
+        if (rc_dl) return rc_dl;
+    }
     if (getenv("HICMI_NNCHAIN_PROFILE")) {
         unsigned long long pr[5] = {0, 0, 0, 0, 0};
         HIPCHK(hipMemcpy(pr, nnchain_prof_ptr(c->d_size), sizeof(pr), hipMemcpyDeviceToHost));
@@ -567,7 +570,10 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
         HIPCHK(hipMalloc(&c->d_sort_scratch, need));
         c->sort_scratch_cap = need;
     }
-    HIPCHK(hipMemcpyAsync(c->d_order, order, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    {
+        int rc_up = upload(c, c->d_order, order, sizeof(int32_t) * (size_t)n);
+        if (rc_up) return rc_up;
+    }
     {
         Timed t(c, F_SORT, (8.0 + 2.0) * (double)n * (double)n);
         launch_sort_rows(c->dC, c->ldc, c->d_order, c->d_np, c->d_seq, (int)n, c->d_sort_scratch, c->dR, ldr, c->stream);
@@ -710,10 +716,12 @@ int hicmi_p2_select(hicmi_ctx* c, const int32_t* sel, int64_t n)
         for (int64_t k = 1; k <= n; k++) H[(size_t)k] = H[(size_t)k - 1] + 1.0 / (double)k;
         rc = ensure(c->d_H, c->h_cap, n + 1);
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(c->d_H, H.data(), sizeof(double) * (size_t)(n + 1), hipMemcpyHostToDevice, c->stream));
+        rc = upload(c, c->d_H, H.data(), sizeof(double) * (size_t)(n + 1));
+        if (rc) return rc;
         HIPCHK(sync_stream(c));
     }
-    HIPCHK(hipMemcpyAsync(c->d_sel, sel, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    rc = upload(c, c->d_sel, sel, sizeof(int32_t) * (size_t)n);
+    if (rc) return rc;
     {
         Timed t(c, F_P2_SELECT, 16.0 * (double)n * (double)n);
         launch_p2_select(c->dC, c->ldc, c->d_sel, (int)n, c->dM2, ld2, c->stream);
@@ -738,9 +746,7 @@ int hicmi_p2_total(hicmi_ctx* c, double* total_out)
         launch_p2_total(c->dM2, c->ld2, (int)c->n2, c->d_partial, c->d_partial + c->n2, c->stream);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(total_out, c->d_partial + c->n2, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(sync_stream(c));
-    return HICMI_OK;
+    return download(c, total_out, c->d_partial + c->n2, sizeof(double));
 }
 
 int hicmi_p2_score(hicmi_ctx* c, const int32_t* perms, int64_t n_cand, int64_t n_used, double total, double* scores_out)
@@ -817,10 +823,9 @@ int hicmi_p2_layout(hicmi_ctx* c, const int32_t* scaf_start, const int32_t* scaf
     c->h_scaf_start.assign(scaf_start, scaf_start + n_scaf);
     c->h_scaf_len.assign(scaf_len, scaf_len + n_scaf);
     c->n_scaf = n_scaf; c->n_arr = 0;
-    HIPCHK(hipMemcpyAsync(c->d_scaf_start, scaf_start, sizeof(int32_t) * (size_t)n_scaf, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_scaf_len, scaf_len, sizeof(int32_t) * (size_t)n_scaf, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(sync_stream(c));
-    return HICMI_OK;
+    int rc_up = upload(c, c->d_scaf_start, scaf_start, sizeof(int32_t) * (size_t)n_scaf);
+    if (rc_up) return rc_up;
+    return upload(c, c->d_scaf_len, scaf_len, sizeof(int32_t) * (size_t)n_scaf);     // consumed in stream order
 }
 
 int hicmi_p2_set_arrangement(hicmi_ctx* c, const int32_t* ids, const uint8_t* rev, int64_t S)
@@ -947,9 +952,10 @@ int hicmi_p2_window_tables(hicmi_ctx* c, int64_t k, const int8_t* orders, int64_
     if (rc) return rc;
     rc = ensure(c->d_orients, c->ori_cap, n_orients * k);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(c->d_orders, orders, (size_t)(n_orders * k), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_orients, orients, (size_t)(n_orients * k), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(sync_stream(c));
+    rc = upload(c, c->d_orders, orders, (size_t)(n_orders * k));
+    if (rc) return rc;
+    rc = upload(c, c->d_orients, orients, (size_t)(n_orients * k));
+    if (rc) return rc;
     c->tab_k = (int)k; c->n_orders = n_orders; c->n_orients = n_orients;
     c->h_orders.assign(orders, orders + n_orders * k);
     c->h_orients.assign(orients, orients + n_orients * k);
