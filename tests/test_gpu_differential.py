@@ -17,6 +17,11 @@ CASES = [
     ("quantised-sparse", 360, 4, 7.0, (0.35, 2), 6, 5, .05),
     ("small-windows", 300, 3, 9.0, None, 4, 3, .01),
     ("k-equals-scan", 280, 2, 11.0, (0.2, 3), 5, 5, .05),
+    # a few more draws of the generator's knobs
+    ("draw-a", 330, 4, 4.0, (0.5, 1), 5, 4, .05),
+    ("draw-b", 250, 2, 14.0, None, 6, 4, .001),
+    ("draw-c", 310, 5, 5.5, (0.1, 2), 4, 4, .05),
+    ("draw-d", 200, 1, 3.0, None, 6, 5, .05),
 ]
 
 # Part 2 alone on the planted chromosomes (the cut scan over-segments maps this small, which would leave no
