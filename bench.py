@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--part1-only", action="store_true", help="BASELINE configs[1]: clustering + cuts only")
     ap.add_argument("--cpu-sample-bins", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-times", choices=["part1", "all"], default="part1",
+                    help="which kernel families get HIP-event timing inside the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -125,7 +127,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.timing_enable(not os.environ.get("HICMI_BENCH_NO_TIMING"))
+    # HIP events around the families that decide the roofline line (nn-chain, row sort, ...).  --kernel-times all
+    # also brackets the hundreds of small launches of the scans and of Part 2, which costs about 10 ms per map.
+    ctx.timing_enable(0 if os.environ.get("HICMI_BENCH_NO_TIMING") else (1 if args.kernel_times == "all" else 2))
     ctx.timing_reset()
     barrier()
     torch.cuda.synchronize()
@@ -189,7 +193,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "launches_per_step": d["launches"] / max(args.steps, 1),
                          "algorithmic_bytes_per_launch": bytes_per_launch},
-            "kernels_ms_per_step": {k: round(v["ms"] / max(args.steps, 1), 3) for k, v in timing.items()},
+            "kernels_ms_per_step": {k: round(v["ms"] / max(args.steps, 1), 3) for k, v in timing.items()
+                                    if v["ms"] > 0 or args.kernel_times == "all"},
         }
         if not args.no_cpu_baseline and world == 1:
             with contextlib.redirect_stdout(io.StringIO()):

@@ -449,7 +449,9 @@ class Context:
         return s.value or 0
 
     def timing_enable(self, on=True):
-        _check(self._lib.hicmi_timing_enable(self._h, 1 if on else 0))
+        """True / 1: HIP events around every kernel family; 2: only around the few-launch Part 1 families
+        (hicmi.h); False / 0: off."""
+        _check(self._lib.hicmi_timing_enable(self._h, int(on)))
         for w in self._workers:
             w.timing_enable(on)
 

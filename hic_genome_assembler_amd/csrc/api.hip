@@ -114,7 +114,7 @@ struct hicmi_ctx {
     char* pin_down = nullptr; size_t pin_down_cap = 0;
 
     // timing
-    bool timing = false;
+    int timing = 0;                                       // 0 off, 1 every family, 2 only the families launched a few times per map
     std::vector<TimedRegion> regions;
     std::vector<hipEvent_t> pool;
     double ms[F_COUNT] = {0}; int64_t launches[F_COUNT] = {0}; double bytes[F_COUNT] = {0};
@@ -128,13 +128,16 @@ struct Timed {
     Timed(hicmi_ctx* ctx, int f, double algo_bytes) : c(ctx), fam(f)
     {
         c->launches[f]++; c->bytes[f] += algo_bytes;
-        if (!c->timing) return;
+        if (!on()) return;
         a = grab(); b = grab();
         hipEventRecord(a, c->stream);
     }
+    // Event pairs around the hundreds of small launches of the scans and of Part 2 cost about 10 ms per 16k map;
+    // mode 2 keeps them for the families that are launched a handful of times (the dominant kernel is one of them).
+    bool on() const { return c->timing == 1 || (c->timing == 2 && fam <= F_RANK_INVERT); }
     ~Timed()
     {
-        if (!c->timing) return;
+        if (!on()) return;
         hipEventRecord(b, c->stream);
         c->regions.push_back({fam, a, b});
     }
@@ -1615,7 +1618,7 @@ int hicmi_timing_enable(hicmi_ctx* c, int on)
     if (!c) return fail(HICMI_EINVAL, "NULL context");
     int rc = resolve_timing(c);
     if (rc) return rc;
-    c->timing = on != 0;
+    c->timing = on < 0 ? 0 : (on > 2 ? 1 : on);
     return HICMI_OK;
 }
 

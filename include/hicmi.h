@@ -243,7 +243,10 @@ int hicmi_plot_downsample(hicmi_ctx *ctx, int kind, const int32_t *order, int64_
 /* ---- timing ----------------------------------------------------------------------------------
  * Accumulated device time (HIP events on the context stream) per kernel family since the last
  * reset, for bench.py's roofline object.  names_out: caller buffer receiving ';'-separated names;
- * ms_out / launches_out / bytes_out: one entry per name (algorithmic bytes as defined in DESIGN.md). */
+ * ms_out / launches_out / bytes_out: one entry per name (algorithmic bytes as defined in DESIGN.md).
+ * hicmi_timing_enable: 0 = off, 1 = every family, 2 = only the Part 1 families that are launched a few times
+ * per map (row sums, distance build, nn-chain, row sort, rank inversion) - launches and bytes are counted in
+ * every mode. */
 int hicmi_timing_reset(hicmi_ctx *ctx);
 int hicmi_timing_enable(hicmi_ctx *ctx, int on);
 int hicmi_timing_get(hicmi_ctx *ctx, char *names_out, int64_t names_cap, double *ms_out,
