@@ -386,15 +386,20 @@ int hicmi_compact(hicmi_ctx* c, const int32_t* keep, int64_t n_keep)
         if (keep[i] < 0 || keep[i] >= c->n || (i && keep[i] <= keep[i - 1])) return fail(HICMI_EINVAL, "keep must be ascending indices in [0, n)");
     HIPCHK(hipSetDevice(c->device));
     int32_t* d_keep = nullptr; double* d_new = nullptr;
+    struct Guard { int32_t*& a; double*& b; ~Guard() { free_dev(a); free_dev(b); } } guard{d_keep, d_new};   // error paths
     HIPCHK(hipMalloc((void**)&d_keep, sizeof(int32_t) * (size_t)n_keep));
     HIPCHK(hipMalloc((void**)&d_new, sizeof(double) * (size_t)n_keep * (size_t)n_keep));
-    HIPCHK(hipMemcpyAsync(d_keep, keep, sizeof(int32_t) * (size_t)n_keep, hipMemcpyHostToDevice, c->stream));
+    {
+        int rc_up = upload(c, d_keep, keep, sizeof(int32_t) * (size_t)n_keep);
+        if (rc_up) return rc_up;
+    }
     launch_compact(c->dC, c->ldc, d_keep, (int)n_keep, d_new, n_keep, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(sync_stream(c));
-    free_dev(d_keep);
+    free_dev(d_keep); d_keep = nullptr;
+    double* kept = d_new; d_new = nullptr;                     // ownership moves to the context below
     drop_matrix_state(c);
-    c->dC = d_new; c->own_c = true; c->n = n_keep; c->ldc = n_keep;
+    c->dC = kept; c->own_c = true; c->n = n_keep; c->ldc = n_keep;
     int rc = alloc_sums(c);
     if (rc) return rc;
     return compute_sums(c);
