@@ -29,6 +29,7 @@ SIGNATURES = {
     "hicmi_stream": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "hicmi_synchronize": (ctypes.c_int, [_vp]),
     "hicmi_set_contacts_host": (ctypes.c_int, [_vp, _vp, c_i64]),
+    "hicmi_set_contacts_host_f32": (ctypes.c_int, [_vp, _vp, c_i64]),
     "hicmi_set_contacts_device": (ctypes.c_int, [_vp, _vp, c_i64, c_i64]),
     "hicmi_contacts_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "hicmi_load_hicpro_matrix": (ctypes.c_int, [ctypes.c_char_p, _vp, c_i64, _vp, ctypes.c_int, ctypes.POINTER(c_i64)]),
@@ -202,6 +203,14 @@ class Context:
 
     # ---- contacts
     def set_contacts(self, mat: np.ndarray):
+        """Upload a square contact matrix: fp64, or fp32 (widened on the device, half the transfer)."""
+        if isinstance(mat, np.ndarray) and mat.dtype == np.float32:
+            mat = np.ascontiguousarray(mat)
+            if mat.ndim != 2 or mat.shape[0] != mat.shape[1]:
+                raise ValueError("contact matrix must be square")
+            _check(self._lib.hicmi_set_contacts_host_f32(self._h, _ptr(mat), mat.shape[0]))
+            self.n = mat.shape[0]
+            return
         mat = np.ascontiguousarray(mat, dtype=np.float64)
         if mat.ndim != 2 or mat.shape[0] != mat.shape[1]:
             raise ValueError("contact matrix must be square")

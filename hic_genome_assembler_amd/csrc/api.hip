@@ -347,6 +347,27 @@ int hicmi_set_contacts_host(hicmi_ctx* c, const double* contacts, int64_t n)
     return alloc_sums(c);
 }
 
+int hicmi_set_contacts_host_f32(hicmi_ctx* c, const float* contacts, int64_t n)
+{
+    // BASELINE configs[4]: a 64,000-bin map stored as fp32 (16.4 GB instead of 32.8 GB on the host and over PCIe).
+    // The values are widened on the device; every stage computes in fp64 on exactly those widened values.
+    if (!c || !contacts || n < 1) return fail(HICMI_EINVAL, "bad arguments");
+    if (n > 65536) return fail(HICMI_EUNSUPPORTED, "n = %lld > 65536 bins: rank matrix is uint16 in this version", (long long)n);
+    HIPCHK(hipSetDevice(c->device));
+    drop_matrix_state(c);
+    c->n = n; c->ldc = n;
+    const size_t cells = (size_t)n * (size_t)n;
+    HIPCHK(hipMalloc((void**)&c->dC, sizeof(double) * cells));
+    c->own_c = true;
+    // the fp32 image is staged in the tail of the fp64 buffer and widened back to front, row block by row block
+    float* d_stage = reinterpret_cast<float*>(c->dC) + cells;
+    HIPCHK(hipMemcpyAsync(d_stage, contacts, sizeof(float) * cells, hipMemcpyHostToDevice, c->stream));
+    launch_widen_f32(d_stage, c->dC, (int64_t)cells, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(sync_stream(c));
+    return alloc_sums(c);
+}
+
 int hicmi_set_contacts_device(hicmi_ctx* c, const double* d_contacts, int64_t n, int64_t ld)
 {
     if (!c || !d_contacts || n < 1 || ld < n) return fail(HICMI_EINVAL, "bad arguments");

@@ -80,6 +80,7 @@ __device__ __forceinline__ double serial_prefix_lds(double* t, int from, int to,
 void launch_row_sums(const double* C, int64_t ldc, int n, double* np_sum, double* seq_sum, hipStream_t s);
 void launch_compact(const double* src, int64_t ld_src, const int32_t* keep, int n_keep, double* dst, int64_t ld_dst,
                     hipStream_t s);
+void launch_widen_f32(const float* src, double* dst, int64_t cells, hipStream_t s);   // src = (float*)dst + cells
 void launch_build_w(const double* C, int64_t ldc, const double* np_sum, int n, double* W, int64_t ldw, hipStream_t s);
 // k_nnchain.hip
 size_t nnchain_workspace_bytes(int n);

@@ -207,4 +207,30 @@ void launch_hyper_flags(const int32_t* x, int nrows, int mode, int L_fixed, int6
     hipLaunchKernelGGL(k_hyper_flags, dim3((nrows + 255) / 256), dim3(256), 0, s, x, nrows, mode, L_fixed, M, psig, sig);
 }
 
+// fp32 -> fp64 in place.  dst has `cells` doubles; the fp32 image sits in the upper half of the same bytes
+// (src = (float*)dst + cells).  Output cell i covers the bytes of input cells 2i - cells and 2i - cells + 1 - none
+// for i < cells / 2, and always cells with a smaller index than i (or i itself, read by the same lane first).  So
+// ascending order is safe, and a chunk [a, b) may run in parallel when everything it overwrites lies below a:
+// 2b - cells - 1 < a, i.e. b <= (a + cells) / 2.  One launch per chunk (stream order between chunks); the chunks
+// halve the remaining distance, about log2(cells) launches.
+__global__ __launch_bounds__(256) void k_widen_f32(const float* __restrict__ src, double* __restrict__ dst, int64_t i0, int64_t i1)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = i0 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < i1; i += stride) dst[i] = (double)src[i];
+}
+
+void launch_widen_f32(const float* src, double* dst, int64_t cells, hipStream_t s)
+{
+    int64_t a = 0;
+    while (a < cells) {
+        int64_t b = a < cells / 2 ? cells / 2 : (a + cells) / 2;
+        if (b <= a) b = a + 1;
+        if (b > cells) b = cells;
+        const int64_t work = b - a;
+        int blocks = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+        hipLaunchKernelGGL(k_widen_f32, dim3(blocks), dim3(256), 0, s, src, dst, a, b);
+        a = b;
+    }
+}
+
 }  // namespace hicmi

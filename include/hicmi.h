@@ -54,6 +54,9 @@ int hicmi_synchronize(hicmi_ctx *ctx);
  * _host copies n*n doubles to the GPU; _device adopts a caller-owned device allocation (leading
  * dimension ld >= n, in elements) without copying - the caller keeps it alive and unchanged. */
 int hicmi_set_contacts_host(hicmi_ctx *ctx, const double *contacts, int64_t n);
+/* The same from an fp32 host matrix (BASELINE.json configs[4]: 64,000 bins stored as fp32): half the host memory and
+ * PCIe traffic; the values are widened to fp64 on the device and every stage computes on exactly those values. */
+int hicmi_set_contacts_host_f32(hicmi_ctx *ctx, const float *contacts, int64_t n);
 int hicmi_set_contacts_device(hicmi_ctx *ctx, const double *d_contacts, int64_t n, int64_t ld);
 /* Device address, size and leading dimension of the context's contact matrix, so that further
  * contexts on the same GPU (e.g. one per chromosome worker thread in Part 2, chromosomes being

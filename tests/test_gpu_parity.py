@@ -643,3 +643,24 @@ def test_api_misuse_is_reported_not_executed(hic):
         # the context is still usable afterwards
         leaves, z = ctx.upgma()
         assert sorted(leaves.tolist()) == list(range(n))
+
+
+def test_fp32_contacts_are_widened_exactly(hic):
+    """BASELINE configs[4] stores the map as fp32: hicmi_set_contacts_host_f32 must leave exactly float64(float32(x))
+    on the device (in-place widening, odd and even cell counts), so every downstream result equals the fp64 path's on
+    the widened matrix."""
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 7, 64, 301, 1000):
+        a32 = (rng.random((n, n)) * 100).astype(np.float32)
+        a32 = ((a32 + a32.T) / 2).astype(np.float32)
+        wide = a32.astype(np.float64)
+        with hic.Context(0) as c32, hic.Context(0) as c64:
+            c32.set_contacts(a32)
+            c64.set_contacts(wide)
+            for got, want in zip(c32.row_sums(), c64.row_sums()):
+                assert np.array_equal(got, want), n
+            if n >= 7:
+                assert np.array_equal(c32.plot_downsample(0, None, n), wide)           # the resident cells themselves
+                l32, z32 = c32.upgma()
+                l64, z64 = c64.upgma()
+                assert np.array_equal(z32, z64) and np.array_equal(l32, l64)
