@@ -487,7 +487,7 @@ def p2_scaffold_bins(ordered, name):
 
 
 # --------------------------------------------------------------------------------- BASELINE sizes: properties
-@pytest.mark.parametrize("n", [16000])
+@pytest.mark.parametrize("n", [16000, 20000])          # 20000: rows longer than one 16384-element sort tile
 def test_full_size_properties(hic, n):
     import torch
     from hic_genome_assembler_amd import synth
@@ -664,3 +664,27 @@ def test_fp32_contacts_are_widened_exactly(hic):
                 l32, z32 = c32.upgma()
                 l64, z64 = c64.upgma()
                 assert np.array_equal(z32, z64) and np.array_equal(l32, l64)
+
+
+def test_row_sort_across_tiles_with_ties(hic):
+    """Rows longer than the 16384-element tile are sorted tile by tile and merged through the scratch buffer; with
+    quantised contacts (heavy ties) the order must still be "stable ascending, reversed" of the similarity row."""
+    import torch
+    n = 16500
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(5)
+    c = torch.randint(0, 40, (n, n), generator=g, device="cuda:0").to(torch.float64)
+    c = torch.triu(c) + torch.triu(c, 1).T
+    c.fill_diagonal_(3.0)
+    torch.cuda.synchronize()
+    with hic.Context(0) as ctx:
+        ctx.set_contacts_device(c.data_ptr(), n, keepalive=c)
+        ctx.row_sums()
+        order = np.random.default_rng(2).permutation(n).astype(np.int32)
+        ctx.rank_matrix(order)
+        for r in (0, 3, 8191, 8192, n - 1):
+            sim = ctx.similarity_row(r)
+            want = np.argsort(sim, kind="stable")[::-1]
+            got = ctx.rank_rows(r, 1)[0].astype(np.int64)
+            assert np.array_equal(got, want), r
+            assert len(np.unique(sim)) < n // 10                               # the ties are really there
