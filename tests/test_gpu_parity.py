@@ -99,6 +99,19 @@ def test_upgma_deferred_columns_any_flush_period(hic, orc, monkeypatch, n, seed,
     assert np.array_equal(leaves, leaves_o)
 
 
+def test_upgma_beyond_one_streaming_pass_bit_exact(hic, orc):
+    """17,000 bins: rows longer than the 16,384 a 1024-lane workgroup streams in eight unrolled trips, 17 epochs,
+    compactions from a matrix that is not a multiple of anything - still SciPy's linkage, bit for bit."""
+    n = 17000
+    rng = np.random.default_rng(42)
+    c = rng.random((n, n), dtype=np.float32).astype(np.float64) + 0.01
+    c = c + c.T
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, c)
+    assert np.array_equal(zraw, zraw_o)
+    assert np.array_equal(z, z_o)
+    assert np.array_equal(leaves, leaves_o)
+
+
 def test_exact_division_by_cluster_size_selftest(hic):
     """k_nnchain's 3-instruction division by (nx+ny) against the '/' operator: 2^29 random operands."""
     with hic.Context(0) as ctx:
