@@ -111,3 +111,31 @@ def test_part2_matches_oracle_on_planted_groups(case, tmp_path):
                            scan_scaffolds, lay.resolution)
         outs[who] = {k: open(f(k)).read() for k in ("chromosomeOrders.txt", "plotOrder.txt")}
     assert outs["gpu"] == outs["oracle"], name
+
+
+def test_part1_matches_oracle_at_6000_bins(tmp_path):
+    """Part 1 at three times the size of the largest reference-generated fixture: UPGMA leaf order, rank-order cut
+    scan with its M-shrinking rescans, noisy-cut filter and scaffold voting - four files, byte for byte (the contacts
+    are handed over in memory; the text loaders have their own tests)."""
+    import hic_oracle as orc
+    from hic_genome_assembler_amd import _lib, scaffoldToChromosomes as p1, synth
+    from hic_genome_assembler_amd.hostio import Bin
+    n = 6000
+    lay = synth.make_layout(n, seed=9)
+    c = synth.dense_contacts(lay, seed=9, sinkhorn_iters=6)
+    sizes = tmp_path / "sizes.txt"
+    sizes.write_text("".join("%s\t%d\n" % (nm, sz) for nm, sz in zip(lay.scaffold_names, lay.scaffold_sizes_bp)))
+    mk = lambda cls: [cls(int(lay.bin_ids[k]), lay.scaffold_names[lay.scaffold_of_bin[k]], int(lay.start[k]), int(lay.stop[k]),
+                          1.0, 0.0) for k in range(n)]  # noqa: E731
+    names = ("dendrogramOrder.txt", "binGroups.txt", "assessment.txt", "chromosomeGroups.txt")
+    for who in ("oracle", "gpu"):
+        (tmp_path / who).mkdir()
+    fo = [str(tmp_path / "oracle" / k) for k in names]
+    fg = [str(tmp_path / "gpu" / k) for k in names]
+    cuts_o = orc.run_part1(None, None, None, str(sizes), *fo, min_size=5, modularity=0.0, psig=.05, preloaded=(c, mk(orc.Bin)))
+    with _lib.Context(0) as ctx:
+        ctx.set_contacts(c)
+        cuts_g = p1.runResident(p1.DeviceMatrix(ctx), mk(Bin), str(sizes), *fg, 5, 0.0, .05)
+    assert list(cuts_g) == list(cuts_o) and len(cuts_g) >= 8
+    for a, b in zip(fg, fo):
+        assert open(a).read() == open(b).read(), a
