@@ -139,3 +139,57 @@ def test_part1_matches_oracle_at_6000_bins(tmp_path):
     assert list(cuts_g) == list(cuts_o) and len(cuts_g) >= 8
     for a, b in zip(fg, fo):
         assert open(a).read() == open(b).read(), a
+
+
+_RESIDENT_RUN = r"""
+import contextlib, io, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+from hic_genome_assembler_amd import _lib, synth, orderGenome as p2, scaffoldToChromosomes as p1
+from hic_genome_assembler_amd.hostio import Bin
+n, out = int(sys.argv[2]), sys.argv[3]
+lay = synth.make_layout(n, seed=4)
+dev = torch.device("cuda", 0)
+c = synth.dense_contacts_torch(lay, dev, seed=4, sinkhorn_iters=8)
+torch.cuda.synchronize()
+sizes = os.path.join(out, "sizes.txt")
+with open(sizes, "w") as fh:
+    fh.write("".join("%s\t%d\n" % (nm, sz) for nm, sz in zip(lay.scaffold_names, lay.scaffold_sizes_bp)))
+bins = [Bin(int(lay.bin_ids[k]), lay.scaffold_names[lay.scaffold_of_bin[k]], int(lay.start[k]), int(lay.stop[k]), 1.0, 0.)
+        for k in range(n)]
+f = lambda k: os.path.join(out, k)
+ctx = _lib.Context(0)
+ctx.set_contacts_device(c.data_ptr(), n, keepalive=c)
+dm = p1.DeviceMatrix(ctx)
+with contextlib.redirect_stdout(io.StringIO()):
+    p1.runResident(dm, bins, sizes, f("dendrogramOrder.txt"), f("binGroups.txt"), f("assessment.txt"), f("chromosomeGroups.txt"),
+                   5, 0.0, .05)
+    p2.runResident(p2.GenomeMatrix(ctx), dm.kept_bins, f("chromosomeGroups.txt"), f("chromosomeOrders.txt"), f("plotOrder.txt"),
+                   6, 5, lay.resolution)
+"""
+
+
+def test_fast_paths_agree_with_the_earlier_ones_at_scale(tmp_path):
+    """An 8,000-bin map (chromosomes of ~900 bins, ~70 scaffolds - far beyond what the Python oracle can order in a
+    test) through the default paths - lock-step device-decided insertion, placement tables, register-blocked sort -
+    and through the earlier implementations of the same stages (host-decided insertion, per-candidate window kernels,
+    LDS sort network, one queue per chromosome), which the golden fixtures validated first.  Same files."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text(_RESIDENT_RUN)
+    variants = {"default": {},
+                "earlier": {"HICMI_P2_HOST_INSERT": "1", "HICMI_P2_WINDOW_DIRECT": "1", "HICMI_SORT_LDS": "1",
+                            "HICMI_PART2_LOCKSTEP": "0"}}
+    texts = {}
+    for name, env in variants.items():
+        out = tmp_path / name
+        out.mkdir()
+        res = subprocess.run([sys.executable, str(script), root, "8000", str(out)], env=dict(os.environ, **env),
+                             capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-2000:]
+        texts[name] = {k: open(out / k).read() for k in ("dendrogramOrder.txt", "binGroups.txt", "chromosomeGroups.txt",
+                                                         "chromosomeOrders.txt", "plotOrder.txt")}
+    assert texts["default"] == texts["earlier"]
+    assert texts["default"]["chromosomeOrders.txt"].count("\n") > 400
