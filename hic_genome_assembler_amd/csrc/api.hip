@@ -590,7 +590,7 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
         free_dev(c->dR); free_dev(c->dRank); free_dev(c->d_order); c->dR = c->dRank = nullptr; c->d_order = nullptr;
         HIPCHK(hipMalloc((void**)&c->dR, sizeof(uint16_t) * (size_t)n * (size_t)ldr));
         HIPCHK(hipMalloc((void**)&c->dRank, sizeof(uint16_t) * (size_t)n * (size_t)ldr));
-        HIPCHK(hipMalloc((void**)&c->d_order, sizeof(int32_t) * (size_t)n));
+        HIPCHK(hipMalloc((void**)&c->d_order, sizeof(int32_t) * 2 * (size_t)n));       // [order][inverse order]
         c->ldr = ldr; c->r_rows = n;
     }
     size_t need = sort_scratch_bytes((int)n);
@@ -600,12 +600,15 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
         c->sort_scratch_cap = need;
     }
     {
-        int rc_up = upload(c, c->d_order, order, sizeof(int32_t) * (size_t)n);
+        std::vector<int32_t> both((size_t)(2 * n));
+        for (int64_t i = 0; i < n; i++) { both[(size_t)i] = order[i]; both[(size_t)(n + order[i])] = (int32_t)i; }
+        int rc_up = upload(c, c->d_order, both.data(), sizeof(int32_t) * both.size());
         if (rc_up) return rc_up;
     }
     {
         Timed t(c, F_SORT, (8.0 + 2.0) * (double)n * (double)n);
-        launch_sort_rows(c->dC, c->ldc, c->d_order, c->d_np, c->d_seq, (int)n, c->d_sort_scratch, c->dR, ldr, c->stream);
+        launch_sort_rows(c->dC, c->ldc, c->d_order, c->d_order + n, c->d_np, c->d_seq, (int)n, c->d_sort_scratch, c->dR, ldr,
+                         c->stream);
     }
     HIPCHK(hipGetLastError());
     {

@@ -98,8 +98,8 @@ void launch_hyper_flags(const int32_t* x, int nrows, int mode, int L_fixed, int6
 int  sort_padded_size(int n);                 // power of two >= n
 int  sort_workgroups(int n);                  // persistent workgroups the sort kernel wants
 size_t sort_scratch_bytes(int n);             // device scratch (keys + indices) for all workgroups
-void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const double* np_sum, const double* seq_sum,
-                      int n, void* scratch, uint16_t* R, int64_t ldr, hipStream_t s);
+void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const int32_t* inv, const double* np_sum,
+                      const double* seq_sum, int n, void* scratch, uint16_t* R, int64_t ldr, hipStream_t s);
 void launch_rank_invert(const uint16_t* R, uint16_t* rank, int64_t ldr, int n, hipStream_t s);
 void launch_similarity_row(const double* C, int64_t ldc, const int32_t* order, const double* np_sum,
                            const double* seq_sum, int n, int row, double* out, hipStream_t s);

@@ -229,7 +229,7 @@ __device__ __forceinline__ void rb_tile_stages(uint64_t (&K)[RB_E], uint32_t (&I
 __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
     const double* __restrict__ C, int64_t ldc, const int32_t* __restrict__ order, const double* __restrict__ np_sum,
     const double* __restrict__ seq_sum, int n, int P, uint64_t* __restrict__ skeys, uint16_t* __restrict__ sidx,
-    uint16_t* __restrict__ R, int64_t ldr)
+    uint16_t* __restrict__ R, int64_t ldr, const int32_t* __restrict__ inv)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* xk = reinterpret_cast<uint64_t*>(smem);                                   // (RB_E / 2) x RB_T keys
@@ -252,9 +252,12 @@ __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
             const int base = t * tile;
 #pragma unroll
             for (int q = 0; q < RB_E; q++) {
+                // the row is read in STORAGE order (coalesced) and each cell carries its position in the leaf order:
+                // the same (key, position) pairs as gathering crow[order[b]], without pulling a 64-byte line per cell
                 const int b = base + RB_E * tid + q;
-                K[q] = (live && b < n) ? key_of(similarity(crow[order[b]], sig, rs)) : ~0ull;
-                I[q] = (uint32_t)(b & 0xffff);
+                const bool real = live && b < n;
+                K[q] = real ? key_of(similarity(crow[b], sig, rs)) : ~0ull;
+                I[q] = real ? (uint32_t)inv[b] : (uint32_t)(b & 0xffff);
             }
             // levels 2 .. RB_E / 2: the direction alternates inside the lane (all indices are compile-time)
 #pragma unroll
@@ -306,8 +309,9 @@ __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
     }
 }
 
-void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const double* np_sum, const double* seq_sum,
-                      int n, void* scratch, uint16_t* R, int64_t ldr, hipStream_t s)
+// order: leaf order (row r of the result is storage row order[r]); inv: its inverse (position of a storage column)
+void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const int32_t* inv, const double* np_sum,
+                      const double* seq_sum, int n, void* scratch, uint16_t* R, int64_t ldr, hipStream_t s)
 {
     static const bool lds_network = getenv("HICMI_SORT_LDS") != nullptr;      // A/B switch: the LDS-resident network
     if (!lds_network) {
@@ -319,7 +323,7 @@ void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const 
         const size_t lds = (size_t)(RB_E / 2) * RB_T * (sizeof(uint64_t) + sizeof(uint16_t));
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_rows_rb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_sort_rows_rb, dim3(wgs), dim3(RB_T), lds, s, C, ldc, order, np_sum, seq_sum, n, P, skeys,
-                           sidx, R, ldr);
+                           sidx, R, ldr, inv);
         return;
     }
     const int P = sort_padded_size(n);
