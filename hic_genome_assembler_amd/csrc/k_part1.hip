@@ -14,71 +14,77 @@ namespace hicmi {
 // NumPy's float64 add.reduce: <=128-element blocks with 8 partial sums, recursive halving above
 // that, inner loop handed at most 8192 elements at a time, chunk results accumulated left to right
 // from 0.0 (restated from NumPy 2.2.6; pinned in tests/test_oracle_cpu.py).
-__device__ __forceinline__ double pw_leaf(const double* __restrict__ a, int n)
+// NumPy's pairwise row sum, one 64-lane workgroup per row: the leaves (<= 128 elements) of a chunk are taken eight at
+// a time, lane (slot, k) = (lane / 8, lane % 8) holding partial sum k of leaf `slot` - consecutive lanes read
+// consecutive cells - then ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by shuffles and the tree over the leaf sums by lane 0
+// (stacks in LDS).  The earlier one-lane-per-row version walked the tree with a private stack, i.e. in scratch memory.
+__global__ __launch_bounds__(64) void k_row_sums_np(const double* __restrict__ C, int64_t ldc, int n,
+                                                    double* __restrict__ np_sum)
 {
-    if (n < 8) {
-        double r = 0.0;
-        for (int i = 0; i < n; i++) r += a[i];
-        return r;
+    __shared__ int leaf_off[MAX_LEAVES], leaf_len[MAX_LEAVES], leaf_dep[MAX_LEAVES];
+    __shared__ double leaf_sum[MAX_LEAVES];
+    __shared__ int s_nleaves, st_a[16], st_b[16], st_c[16];
+    __shared__ double st_v[16];
+    const int row = blockIdx.x, lane = threadIdx.x, slot = lane >> 3, k = lane & 7;
+    const double* __restrict__ a = C + (int64_t)row * ldc;
+    double acc = 0.0;                                   // chunk results accumulate left to right from 0.0
+    for (int c0 = 0; c0 < n; c0 += 8192) {
+        const int clen = n - c0 < 8192 ? n - c0 : 8192;
+        __syncthreads();
+        if (lane == 0) s_nleaves = enumerate_leaves(c0, clen, leaf_off, leaf_len, leaf_dep, st_a, st_b, st_c);
+        __syncthreads();
+        const int nl = s_nleaves;
+        for (int l0 = 0; l0 < nl; l0 += 8) {
+            const int l = l0 + slot;
+            int o = 0, m = 0, lim = 0;
+            if (l < nl) { o = leaf_off[l]; m = leaf_len[l]; lim = m - (m % 8); }
+            double vals[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) vals[q] = (l < nl && m >= 8 && q * 8 < lim) ? a[o + q * 8 + k] : 0.0;
+            double r = vals[0];
+#pragma unroll
+            for (int q = 1; q < 16; q++) if (q * 8 < lim) r += vals[q];
+            double s1 = r + __shfl_down(r, 1, 64);
+            double s2 = s1 + __shfl_down(s1, 2, 64);
+            double s3 = s2 + __shfl_down(s2, 4, 64);
+            if (l < nl && k == 0) {
+                double res;
+                if (m < 8) { res = 0.0; for (int i = 0; i < m; i++) res += a[o + i]; }
+                else { res = s3; for (int i = lim; i < m; i++) res += a[o + i]; }
+                leaf_sum[l] = res;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) acc += combine_leaves(nl, leaf_sum, leaf_dep, st_v, st_a);
     }
-    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
-    int i, lim = n - (n % 8);
-    for (i = 8; i < lim; i += 8) {
-        r0 += a[i + 0]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
-        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
-    }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; i++) res += a[i];
-    return res;
+    if (lane == 0) np_sum[row] = acc;
 }
 
-__device__ double pw_chunk(const double* __restrict__ a, int n)   // n <= 8192
+// Python's builtin sum(): strictly left to right, one lane per row (the chain cannot be split); 16-byte loads, eight
+// cells fetched ahead of the adds.
+__global__ __launch_bounds__(64) void k_row_sums_seq(const double* __restrict__ C, int64_t ldc, int n,
+                                                     double* __restrict__ seq_sum)
 {
-    struct Frame { int off, len, n2, stage; double left; };
-    Frame st[10];
-    int sp = 1;
-    double ret = 0.0;
-    st[0] = {0, n, 0, 0, 0.0};
-    while (sp > 0) {
-        Frame& f = st[sp - 1];
-        if (f.len <= 128) { ret = pw_leaf(a + f.off, f.len); sp--; continue; }
-        if (f.stage == 0) {
-            int n2 = f.len / 2;
-            n2 -= n2 % 8;
-            f.n2 = n2; f.stage = 1;
-            st[sp++] = {f.off, n2, 0, 0, 0.0};
-        } else if (f.stage == 1) {
-            f.left = ret; f.stage = 2;
-            st[sp++] = {f.off + f.n2, f.len - f.n2, 0, 0, 0.0};
-        } else {
-            ret = f.left + ret;
-            sp--;
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= n) return;
+    const double* __restrict__ a = C + (int64_t)row * ldc;          // ldc is a multiple of 2 cells or the row is read cell-wise
+    double s = 0.0;
+    int i = 0;
+    if ((((uintptr_t)a) & 15u) == 0) {
+        for (; i + 8 <= n; i += 8) {
+            const double2 v0 = *reinterpret_cast<const double2*>(a + i), v1 = *reinterpret_cast<const double2*>(a + i + 2);
+            const double2 v2 = *reinterpret_cast<const double2*>(a + i + 4), v3 = *reinterpret_cast<const double2*>(a + i + 6);
+            s += v0.x; s += v0.y; s += v1.x; s += v1.y; s += v2.x; s += v2.y; s += v3.x; s += v3.y;
         }
     }
-    return ret;
-}
-
-// One lane per row; a lane streams its own row, so every fetched line is fully consumed by it.
-__global__ __launch_bounds__(64) void k_row_sums(const double* __restrict__ C, int64_t ldc, int n,
-                                                 double* __restrict__ np_sum, double* __restrict__ seq_sum)
-{
-    int row = blockIdx.x * 64 + threadIdx.x;
-    if (row >= n) return;
-    const double* a = C + (int64_t)row * ldc;
-    double acc = 0.0;
-    for (int c = 0; c < n; c += 8192) {
-        int m = n - c < 8192 ? n - c : 8192;
-        acc += pw_chunk(a + c, m);
-    }
-    np_sum[row] = acc;
-    double s = 0.0;                       // builtin sum(): strictly left to right
-    for (int i = 0; i < n; i++) s += a[i];
+    for (; i < n; i++) s += a[i];
     seq_sum[row] = s;
 }
 
 void launch_row_sums(const double* C, int64_t ldc, int n, double* np_sum, double* seq_sum, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_row_sums, dim3((n + 63) / 64), dim3(64), 0, s, C, ldc, n, np_sum, seq_sum);
+    hipLaunchKernelGGL(k_row_sums_np, dim3(n), dim3(64), 0, s, C, ldc, n, np_sum);
+    hipLaunchKernelGGL(k_row_sums_seq, dim3((n + 63) / 64), dim3(64), 0, s, C, ldc, n, seq_sum);
 }
 
 // removeRows (S2C:100-136): dst = src[keep][:, keep]

@@ -49,43 +49,7 @@ __device__ __forceinline__ double wave_sum(double v)
 // workgroup owns one diagonal, 8 lanes own one leaf (lane k = partial sum k: at most 16 dependent
 // adds), the fixed ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) tree is three shuffles, and only the handful
 // of leaf results are combined serially along NumPy's recursion tree.
-static constexpr int MAX_LEAVES = 64;                  // an 8192-element chunk splits into <= 64 leaves
-
-// Leaves of NumPy's pairwise recursion over [off, off+len), in order, with their depth in the
-// recursion tree.  The explicit stack lives in LDS (st_off/st_len/st_dep: 16 entries each): private
-// arrays indexed at run time would be spilled to scratch memory, a global-memory round trip per access.
-__device__ __forceinline__ int enumerate_leaves(int off, int len, int* leaf_off, int* leaf_len, int* leaf_dep,
-                                                int* st_off, int* st_len, int* st_dep)
-{
-    int sp = 1, n = 0;
-    st_off[0] = off; st_len[0] = len; st_dep[0] = 0;
-    while (sp > 0) {
-        sp--;
-        const int o = st_off[sp], l = st_len[sp], d = st_dep[sp];
-        if (l <= 128) { leaf_off[n] = o; leaf_len[n] = l; leaf_dep[n] = d; n++; continue; }
-        int n2 = l / 2;
-        n2 -= n2 % 8;
-        st_off[sp] = o + n2; st_len[sp] = l - n2; st_dep[sp] = d + 1; sp++;      // right half (processed second)
-        st_off[sp] = o; st_len[sp] = n2; st_dep[sp] = d + 1; sp++;                // left half
-    }
-    return n;
-}
-
-// left + right at every split of the same tree: leaves arrive in order; whenever the two newest partial
-// results sit at the same depth they are the two halves of one node (left first) and are replaced by
-// their sum one level up.  val/dep: LDS stacks of 16 entries.
-__device__ __forceinline__ double combine_leaves(int n_leaves, const double* leaf_sum, const int* leaf_dep, double* val,
-                                                 int* dep)
-{
-    int sp = 0;
-    for (int l = 0; l < n_leaves; l++) {
-        double v = leaf_sum[l];
-        int d = leaf_dep[l];
-        while (sp > 0 && dep[sp - 1] == d) { v = val[sp - 1] + v; d--; sp--; }
-        val[sp] = v; dep[sp] = d; sp++;
-    }
-    return val[0];
-}
+// enumerate_leaves / combine_leaves / MAX_LEAVES: hicmi_internal.h (shared with the row sums of k_part1.hip)
 
 // Where position t of a candidate order sits in the selection: an index list with, optionally, one
 // scaffold (selection range [new_start, new_start + L), reversed or not) spliced in at position P - the
