@@ -300,8 +300,7 @@ def writeBinGroupingsToFile(coords, binList, outFile):
     bounds = [0] + [int(c) for c in coords] + [len(binList)]
     groups, text = [], []
     for g in range(len(bounds) - 1):
-        lines = ["\t".join((str(b.ID), b.chrom, str(b.start), str(b.stop), str(b.bias)))
-                 for b in binList[bounds[g]:bounds[g + 1]]]
+        lines = [f"{b.ID}\t{b.chrom}\t{b.start}\t{b.stop}\t{b.bias}" for b in binList[bounds[g]:bounds[g + 1]]]
         text.append("### Chromosome group " + str(g + 1) + " ###\n")
         text.extend(l + "\n" for l in lines)
         groups.append(lines)
@@ -359,7 +358,15 @@ def _assess_group(pairs, scaffDict, out, percentToAssign):
 
 
 def _pairs_of_lines(cList):
-    return [tuple(line.split("\t", 2)[:2]) for line in cList]
+    """(bin, scaffold) of every bin-grouping line; entries that already are such pairs pass through."""
+    return [line if isinstance(line, tuple) else tuple(line.split("\t", 2)[:2]) for line in cList]
+
+
+def _bin_group_pairs(coords, binList):
+    """What readBinGroupingsFromFile + the split in assessChromosomeClustering extract from the bin-grouping file:
+    per group the (bin ID text, scaffold) pairs - taken from the bins themselves."""
+    bounds = [0] + [int(c) for c in coords] + [len(binList)]
+    return [[(str(b.ID), b.chrom) for b in binList[bounds[g]:bounds[g + 1]]] for g in range(len(bounds) - 1)]
 
 
 def assessClusterList(cList, scaffDict, outFile, percentToAssign=51.):
@@ -477,7 +484,8 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
                 new_order, cutIndices = louvain.modularity_remaining_data(louvain.log_transform(sim_tail), binList,
                                                                           cutIndices, n_rounds=louvainRounds)
                 adjMat, binList = reorderMatrix(adjMat, binList, new_order)
-        binGroups = writeBinGroupingsToFile(cutIndices, binList, binGroupFile)
+        writeBinGroupingsToFile(cutIndices, binList, binGroupFile)
+        binGroups = _bin_group_pairs(cutIndices, binList)
         print("Total run-time to identify chromosome boundaries = " + str(time.time() - t0))
         t0 = time.time()
         fastaSizeDict = readSizeFileToDict(hicProScaffSizeFile)

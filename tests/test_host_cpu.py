@@ -187,6 +187,7 @@ def test_intermediate_files_round_trip(tmp_path):
     for cuts in ([], [9], [9, 30, 31]):
         groups = s2c.writeBinGroupingsToFile(cuts, bins, str(tmp_path / "g.txt"))
         assert s2c.readBinGroupingsFromFile(str(tmp_path / "g.txt")) == groups
+        assert [s2c._pairs_of_lines(g) for g in groups] == s2c._bin_group_pairs(cuts, bins)
         assert sum(len(g) for g in groups) == 60 and len(groups) == len(cuts) + 1
     # the voting report: per-group helper and whole-genome function agree with a direct restatement
     groups = s2c.writeBinGroupingsToFile([9, 30], bins, str(tmp_path / "g.txt"))
