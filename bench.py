@@ -80,6 +80,11 @@ def main():
     ap.add_argument("--part1-only", action="store_true", help="BASELINE configs[1]: clustering + cuts only")
     ap.add_argument("--cpu-sample-bins", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-map", action="store_true",
+                    help="N > 1: ONE map on all ranks (strong scaling) - Part 1 replicated, Part 2's chromosomes dealt "
+                         "to the ranks, orders all-gathered; the default is one independent map per rank (weak)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: rehearse the multi-rank flow with several ranks on one GPU")
     ap.add_argument("--kernel-times", choices=["part1", "all"], default="part1",
                     help="which kernel families get HIP-event timing inside the timed region")
     args = ap.parse_args()
@@ -88,17 +93,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
+    if args.backend == "gloo":                          # rehearsal: more ranks than GPUs share the cards
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     from hic_genome_assembler_amd import _lib, dist, synth
-    dist.init("nccl", device=dev)                       # RCCL; no-op for one process
+    dist.init(args.backend, device=dev)                 # RCCL; no-op for one process
+    one_map = args.one_map and world > 1
+    shard = (rank, world) if one_map else None
+    map_seed = 1 if one_map else 1 + rank
+    reduce_dev = dev if args.backend == "nccl" else None
     from hic_genome_assembler_amd import orderGenome as p2, scaffoldToChromosomes as p1
     from hic_genome_assembler_amd.hostio import Bin
 
     n = args.bins
-    lay = synth.make_layout(n, seed=1 + rank)
-    contacts = synth.dense_contacts_torch(lay, dev, seed=1 + rank, sinkhorn_iters=12)
+    lay = synth.make_layout(n, seed=map_seed)
+    contacts = synth.dense_contacts_torch(lay, dev, seed=map_seed, sinkhorn_iters=12)
     torch.cuda.synchronize()
     work = tempfile.mkdtemp(prefix="hicbench_r%d_" % rank)
     sizes = os.path.join(work, "synth.sizes")
@@ -119,7 +130,7 @@ def main():
             if not args.part1_only:
                 p2.runResident(p2.GenomeMatrix(ctx), dm.kept_bins, f("chromosomeGroups.txt"),
                                f("chromosomeOrders.txt"), f("plotOrder.txt"), args.n_scaffolds, args.scan_scaffolds,
-                               lay.resolution)
+                               lay.resolution, shard=shard)
         last["part2_s"] = time.perf_counter() - ta - last["part1_s"]
         last["cuts"] = cuts
 
@@ -140,13 +151,13 @@ def main():
     ctx.synchronize()
     torch.cuda.synchronize()
     barrier()
-    elapsed = dist.max_over_ranks(time.perf_counter() - t0, device=dev)
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0, device=reduce_dev)
     timing = ctx.timing()
     ctx.timing_enable(False)
 
     if rank == 0:
         ms_per_step = elapsed / max(args.steps, 1) * 1e3
-        value = world * n / (ms_per_step / 1e3)
+        value = (1 if one_map else world) * n / (ms_per_step / 1e3)
         # Part 2 families are summed over the concurrent worker streams (and the queued insertion is timed as
         # one region per chromosome), so their wall-clock share is about 1/workers of the sum
         workers = max(1, min(p2.WORKERS, 8))
@@ -175,7 +186,8 @@ def main():
             "metric": "Part1+Part2 wall-clock (s) and bins/s on N x N contact map" if not args.part1_only
                       else "Part1 wall-clock (s) and bins/s on N x N contact map",
             "value": value, "unit": "bins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if one_map else "weak",
+            "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("%d-bin synthetic ICE-balanced map, %s on 1xMI355X per rank "
                                     "(BASELINE.json configs[%d]), contacts resident in HBM"
@@ -188,7 +200,9 @@ def main():
                        "last_step_part1_s": round(last.get("part1_s", 0.0), 4),
                        "last_step_part2_s": round(last.get("part2_s", 0.0), 4),
                        "part2_workers": p2.WORKERS,
-                       "parallelism": "1 map per GPU, no collective" if world > 1 else "single GPU"},
+                       "parallelism": ("one map over %d GPUs: Part 1 replicated, Part 2 chromosomes dealt to the ranks, "
+                                       "object all-gather of the orders" % world) if one_map
+                                      else "1 map per GPU, no collective" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": fam, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "launches_per_step": d["launches"] / max(args.steps, 1),

@@ -637,15 +637,34 @@ def orderChromosome(chromGroup, matrix: GenomeMatrix, binList, nScaffolds=6, sca
     return _finishChromosome(state, orderedScaffolds, bestCost, matrix, binList)
 
 
+def chromosomesOfRank(chromList, rank, world):
+    """The chromosomes one rank orders when a single map is spread over ``world`` processes: largest first, each
+    to the rank with the least work so far (work ~ bins squared, the size of the chromosome's sub-matrix; ties go
+    to the lowest rank).  Every rank computes the same deal from the same group file - no exchange needed."""
+    load = [0] * world
+    mine = []
+    for i in sorted(range(len(chromList)), key=lambda i: (-len(chromList[i]), i)):
+        r = min(range(world), key=lambda k: (load[k], k))
+        load[r] += len(chromList[i]) ** 2
+        if r == rank:
+            mine.append(i)
+    return sorted(mine)
+
+
 def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds=6, scanScaffolds=5, plotChrom=True,
-                showPlot=True, savePlotDir=False, plotTitleSuffix=False):
+                showPlot=True, savePlotDir=False, plotTitleSuffix=False, shard=None):
     """OG:591-628.  Chromosomes are independent (OG:608-612), so they are ordered concurrently:
     one host thread + one libhicmi context (own HIP stream, own scratch) per chromosome in flight,
     all reading the same device-resident contact matrix.  Results are collected in file order.
-    The per-chromosome figures (OG:615-622) are drawn afterwards from the device-resident matrix."""
+    The per-chromosome figures (OG:615-622) are drawn afterwards from the device-resident matrix.
+
+    ``shard=(rank, world)``: one map over several GPUs.  Every rank holds the map, orders only the
+    chromosomes ``chromosomesOfRank`` deals to it and draws their figures; one object all-gather of the ordered
+    scaffold lists (names, orientations, bin IDs: a few KB) gives every rank the whole genome order."""
     t0 = time.time()
     t0p = time.perf_counter()
-    n_workers = 1 if SCORE_HOOK is not None else max(1, min(WORKERS, len(chromList)))
+    indices = list(range(len(chromList))) if shard is None else chromosomesOfRank(chromList, shard[0], shard[1])
+    n_workers = 1 if SCORE_HOOK is not None else max(1, min(WORKERS, len(indices)))
     matrix.bin_index(binList)
 
     def one(i, m):
@@ -661,15 +680,16 @@ def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds
         return res
 
     if n_workers == 1 or not hasattr(matrix.ctx, "workers"):
-        fullGenomeOrder = [one(i, matrix) for i in range(len(chromList))]
+        done = {i: one(i, matrix) for i in indices}
     elif LOCKSTEP and hasattr(matrix.ctx, "p2_insert_all_multi"):
         # Three phases over ALL chromosomes, one context each: (1) selection + brute force on worker threads,
         # (2) every chromosome's insertion loop in lock step, decided on the device - one queue of launches
         # serving all of them (hicmi_p2_insert_all_multi), (3) the sliding-window rounds on worker threads.
-        lanes = [matrix] + [GenomeMatrix(c) for c in matrix.ctx.workers(len(chromList) - 1)]
+        lanes = [matrix] + [GenomeMatrix(c) for c in matrix.ctx.workers(len(indices) - 1)]
         for m in lanes[1:]:
             m._bin_index, m._bin_index_src = matrix._bin_index, matrix._bin_index_src
-        todo = sorted(range(len(chromList)), key=lambda i: -len(chromList[i]))     # largest first
+        lanes = dict(zip(indices, lanes))
+        todo = sorted(indices, key=lambda i: -len(chromList[i]))                    # largest first
         marks = [time.perf_counter()]
 
         def start(i):
@@ -702,13 +722,12 @@ def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds
             sys.stderr.write("[hicmi] part2 lock step: start %.1f ms, insertion %.1f ms (%d chromosomes), scan %.1f ms\n"
                              % ((marks[1] - marks[0]) * 1e3, (marks[2] - marks[1]) * 1e3, len(jobs),
                                 (marks[3] - marks[2]) * 1e3))
-        fullGenomeOrder = [done[i] for i in range(len(chromList))]
     else:
         lanes = [matrix] + [GenomeMatrix(c) for c in matrix.ctx.workers(n_workers - 1)]
         for m in lanes[1:]:
             m._bin_index, m._bin_index_src = matrix._bin_index, matrix._bin_index_src
         free = list(lanes)
-        todo = sorted(range(len(chromList)), key=lambda i: -len(chromList[i]))     # largest first
+        todo = sorted(indices, key=lambda i: -len(chromList[i]))                    # largest first
 
         def run(i):
             m = free.pop()
@@ -718,15 +737,18 @@ def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds
                 free.append(m)
         with ThreadPoolExecutor(max_workers=n_workers) as pool:
             done = dict(pool.map(run, todo))
-        fullGenomeOrder = [done[i] for i in range(len(chromList))]
+    if shard is not None:
+        from . import dist
+        done = dist.gather_results(done)
+    fullGenomeOrder = [done[i] for i in range(len(chromList))]
     print("RunTime for total genome = " + str(time.time() - t0))
     if plotChrom is True and plotModule.plots_enabled(savePlotDir):
         # OG:615-622: one figure per chromosome.  The device reductions run here one after the other (a context
         # is not thread-safe), the drawing and PNG encoding on worker threads.
         where = matrix.bin_index(binList)
         todo = []
-        for i, chromOrder in enumerate(fullGenomeOrder):
-            rows = [where[b] for s in chromOrder for b in s.binList]
+        for i in indices:
+            rows = [where[b] for s in fullGenomeOrder[i] for b in s.binList]
             if len(rows) == 0:
                 continue
             img = plotModule.DeviceImage(matrix.ctx, 0, rows)
@@ -808,16 +830,18 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, chromosomeGroup
 
 
 def runResident(adjMat: GenomeMatrix, binList, chromosomeGroupFile, chromosomeOrderFile, plotOrderFile,
-                nScaffolds, scanScaffolds, resolution, savePlotDir=False, plotTitleSuffix=False):
+                nScaffolds, scanScaffolds, resolution, savePlotDir=False, plotTitleSuffix=False, shard=None):
     """OG:691-709 on contacts that are already resident in HBM (what bench.py times).  ``binList``
     gives the bin of every row of the device matrix; bins that Part 1 did not assign to a group are
     simply never selected, which is what the reference's re-load restricted to grouped bins
-    (OG:688-690) amounts to."""
+    (OG:688-690) amounts to.  ``shard=(rank, world)``: see ``orderGenome``; every rank returns the whole order
+    and rank 0 writes the two files."""
     with paused_gc():
         chromosomeList = readChromsFromFile(chromosomeGroupFile)
         orderedChromosomes = orderGenome(adjMat, chromosomeList, binList, resolution, nScaffolds=nScaffolds,
                                          scanScaffolds=scanScaffolds, plotChrom=True, showPlot=False,
-                                         savePlotDir=savePlotDir, plotTitleSuffix=plotTitleSuffix)
-        writeScaffoldOrderingsToFile(orderedChromosomes, chromosomeOrderFile)
-        writeBinIDsOrderingToFile([s for group in orderedChromosomes for s in group], plotOrderFile)
+                                         savePlotDir=savePlotDir, plotTitleSuffix=plotTitleSuffix, shard=shard)
+        if shard is None or shard[0] == 0:
+            writeScaffoldOrderingsToFile(orderedChromosomes, chromosomeOrderFile)
+            writeBinIDsOrderingToFile([s for group in orderedChromosomes for s in group], plotOrderFile)
     return orderedChromosomes
