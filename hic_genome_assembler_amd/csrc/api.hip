@@ -1352,7 +1352,7 @@ int queue_insertions(hicmi_ctx* lead, const std::vector<InsJob*>& jobs)
             d.T_total = c->d_ins_T; d.T_cand = c->d_ins_T + n_max; d.work = c->d_ins_T + (1 + (int64_t)INS_MAXC) * n_max;
             d.partial = c->d_ins_partial; d.log = log + t;
             d.n_arr = (int32_t)n_arr; d.S = (int32_t)(job.S + t); d.L = L; d.new_start = c->h_scaf_start[(size_t)nid];
-            d.new_id = nid; d.active = 1; d.step = (int32_t)t;
+            d.new_id = nid; d.active = 1; d.step = (int32_t)t; d.last = t == n_steps - 1;
             max_n_used[(size_t)t] = std::max(max_n_used[(size_t)t], (int)(n_arr + L));
             max_S[(size_t)t] = std::max(max_S[(size_t)t], d.S);
             max_n_arr[(size_t)t] = std::max(max_n_arr[(size_t)t], (int)n_arr);
@@ -1369,9 +1369,8 @@ int queue_insertions(hicmi_ctx* lead, const std::vector<InsJob*>& jobs)
         for (int64_t t = 0; t < steps_max; t++) {
             const InsStep* st_t = lead->d_ins_steps + t * nj;
             const int nu = max_n_used[(size_t)t];
-            launch_insb_diag_total(st_t, nj, nu, lead->stream);
             launch_insb_fast(st_t, nj, max_S[(size_t)t], max_n_arr[(size_t)t], NB, lead->stream);
-            launch_insb_shortlist(st_t, nj, nu, max_S[(size_t)t], NB, kNearTop, max_c, lead->stream);
+            launch_insb_shortlist(st_t, nj, max_S[(size_t)t], NB, kNearTop, max_c, lead->stream);
             launch_insb_diag_cand(st_t, nj, nu, lead->stream);
             launch_insb_cost(st_t, nj, nu, lead->stream);
             launch_insb_apply(st_t, nj, nu, lead->stream);
@@ -1381,6 +1380,24 @@ int queue_insertions(hicmi_ctx* lead, const std::vector<InsJob*>& jobs)
     std::vector<unsigned char> blob(blob_bytes);
     rc = download(lead, blob.data(), lead->d_ins_blob, blob_bytes);
     if (rc) return rc;
+    if (getenv("HICMI_PART2_PROFILE")) {                   // how many lock steps needed a literal tie-break at all
+        int64_t hist[5] = {0, 0, 0, 0, 0}, all_direct = 0;       // [0] = taken directly (one candidate near the top)
+        for (int64_t t = 0; t < steps_max; t++) {
+            int mx = -1;
+            for (int j = 0; j < nj; j++) {
+                if (t >= jobs[(size_t)j]->n_new - jobs[(size_t)j]->t) continue;
+                const InsLog* hl = reinterpret_cast<const InsLog*>(blob.data() + blob_off[(size_t)j] + sizeof(InsState));
+                const int ns = hl[t].n_short;
+                hist[ns < 0 ? 0 : (ns > 3 ? 4 : ns + 1)]++;
+                mx = std::max(mx, ns);
+            }
+            if (mx < 0) all_direct++;
+        }
+        fprintf(stderr, "[hicmi] insertion short lists: direct %lld, literal with 0:%lld 1:%lld 2:%lld 3+:%lld candidates; "
+                        "lock steps without any literal pass: %lld of %lld\n",
+                (long long)hist[0], (long long)hist[1], (long long)hist[2], (long long)hist[3], (long long)hist[4],
+                (long long)all_direct, (long long)steps_max);
+    }
     for (int j = 0; j < nj; j++) {
         InsJob& job = *jobs[(size_t)j];
         const int64_t n_steps = job.n_new - job.t;

@@ -190,25 +190,25 @@ static constexpr int INS_MAXC = 8;       // candidates re-scored literally per s
 struct InsState {
     int32_t fail;                        // -1, or the first step the device could not decide
     int32_t n_short;                     // short-listed candidates of the current step
+    int32_t direct, pad;                 // 1: the step has ONE candidate near the top - slot 0 is taken without a literal score
     int32_t gap[INS_MAXC], rev[INS_MAXC], idx[INS_MAXC];   // idx = position in the reference's enumeration
-    double total;                        // literal total of the step (OG:343)
+    double total;                        // literal total of the step (OG:343), formed when a literal pass runs
     double lit[INS_MAXC];                // literal scores of the short list
 };
-struct InsLog { int32_t gap, rev; double best; };
+struct InsLog { int32_t gap, rev; double best; int32_t n_short, pad; };
 struct InsStep {
     const double* M2; const double* H; int64_t ld2;
     const int32_t* pos_cur; int32_t* pos_nxt;            // arrangement as bin order (ping-pong)
     const int32_t* packed_cur; int32_t* packed_nxt;       // [S ids][S+1 prefix positions][S reversed flags]
     double *T_total, *T_cand, *work, *partial;
     InsState* st; InsLog* log;                            // log: this step's entry
-    int32_t n_arr, S, L, new_start, new_id, active, step, pad;
+    int32_t n_arr, S, L, new_start, new_id, active, step, last;   // last: the job's final step (its score is returned)
 };
 // k_part2.hip / k_part2_search.hip / k_part2_insert.hip: one launch serves all chromosomes (blockIdx.y)
 void launch_insb_reset(const InsStep* steps, int n_chrom, hipStream_t s);
-void launch_insb_diag_total(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s);
 void launch_insb_fast(const InsStep* steps, int n_chrom, int max_S, int max_n_arr, int n_base_blocks, hipStream_t s);
-void launch_insb_shortlist(const InsStep* steps, int n_chrom, int max_n_used, int max_S, int n_base_blocks, double near_top,
-                           int max_c, hipStream_t s);
+void launch_insb_shortlist(const InsStep* steps, int n_chrom, int max_S, int n_base_blocks, double near_top, int max_c,
+                           hipStream_t s);
 void launch_insb_diag_cand(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s);
 void launch_insb_cost(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s);
 void launch_insb_apply(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s);

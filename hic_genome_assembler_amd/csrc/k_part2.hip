@@ -232,26 +232,22 @@ void launch_p2_score_exact(const double* M2, int64_t ld2, const int32_t* perms, 
 }
 
 // ---- lock-step insertion (k_part2_insert.hip): the same bodies, one layer of workgroups per chromosome ----
-// literal total of "arrangement, then the new scaffold forward" (OG:484-487 -> OG:343): T_total[off]
-__global__ __launch_bounds__(64) void k_insb_diag_total(const InsStep* __restrict__ steps)
-{
-    const InsStep& d = steps[blockIdx.y];
-    if (!d.active || d.st->fail >= 0) return;
-    const int n_used = d.n_arr + d.L, off = diag_of_block(blockIdx.x);
-    if (off >= n_used) return;
-    const IndexMap m = {d.pos_cur, d.n_arr, 0x3fffffff, d.new_start, 0};
-    const double acc = diag_sum_body(d.M2, d.ld2, m, n_used, off);
-    if (threadIdx.x == 0) d.T_total[off] = acc;
-}
-
-// diagonal sums of the short-listed candidates (each workgroup walks the few of its chromosome)
+// The literal pass of a step, run only for chromosomes whose short list needs it (k_insb_shortlist):
+// diagonal sums of "arrangement, then the new scaffold forward" (OG:484-487 -> OG:343: T_total, the step's total)
+// and of the short-listed candidates (each workgroup walks the few of its chromosome)
 __global__ __launch_bounds__(64) void k_insb_diag_cand(const InsStep* __restrict__ steps)
 {
     const InsStep& d = steps[blockIdx.y];
     if (!d.active || d.st->fail >= 0) return;
+    const int ns = d.st->n_short;
+    if (ns == 0) return;
     const int n_used = d.n_arr + d.L, off = diag_of_block(blockIdx.x);
     if (off >= n_used) return;
-    const int ns = d.st->n_short;
+    {
+        const IndexMap m = {d.pos_cur, d.n_arr, 0x3fffffff, d.new_start, 0};
+        const double acc = diag_sum_body(d.M2, d.ld2, m, n_used, off);
+        if (threadIdx.x == 0) d.T_total[off] = acc;
+    }
     for (int q = 0; q < ns; q++) {
         const IndexMap m = {d.pos_cur, d.packed_cur[d.S + d.st->gap[q]], d.L, d.new_start, d.st->rev[q]};
         const double acc = diag_sum_body(d.M2, d.ld2, m, n_used, off);
@@ -261,18 +257,32 @@ __global__ __launch_bounds__(64) void k_insb_diag_cand(const InsStep* __restrict
 
 __global__ __launch_bounds__(256) void k_insb_cost(const InsStep* __restrict__ steps)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ic[];
+    __shared__ double s_total;
     const InsStep& d = steps[blockIdx.y];
     if (!d.active || d.st->fail >= 0) return;
     const int cand = blockIdx.x;
     if (cand >= d.st->n_short) return;
     const int n_used = d.n_arr + d.L;
-    cost_exact_body(d.T_cand + (int64_t)cand * n_used, n_used, d.st->total, d.work + (int64_t)cand * n_used, d.st->lit + cand);
-}
-
-void launch_insb_diag_total(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s)
-{
-    if (max_n_used < 2) return;
-    hipLaunchKernelGGL(k_insb_diag_total, dim3(diag_grid(max_n_used), n_chrom), dim3(64), 0, s, steps);
+    {
+        // the step's literal total: Python sum(), 0 + T_1 + T_2 + ...  (OG:343) - every candidate's workgroup
+        // forms the same value
+        double* t = reinterpret_cast<double*>(smem_ic);
+        const bool staged = n_used <= SERIAL_LDS_MAX;
+        if (staged) {
+            for (int i = threadIdx.x; i < n_used; i += 256) t[i] = d.T_total[i];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            double acc = 0.0;
+            if (staged) acc = serial_sum_lds(t, 1, n_used, 0.0);
+            else for (int i = 1; i < n_used; i++) acc += d.T_total[i];
+            s_total = acc;
+            if (cand == 0) d.st->total = acc;
+        }
+        __syncthreads();
+    }
+    cost_exact_body(d.T_cand + (int64_t)cand * n_used, n_used, s_total, d.work + (int64_t)cand * n_used, d.st->lit + cand);
 }
 
 void launch_insb_diag_cand(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s)

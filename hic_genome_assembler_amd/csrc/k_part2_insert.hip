@@ -6,12 +6,14 @@
 // of bins of the arrangement are known before any score is - only the gap and the orientation chosen
 // are not, and those stay in device memory.  The host builds one InsStep record per (step, chromosome)
 // (hicmi_internal.h) and every kernel takes the records of one step; blockIdx.y = chromosome:
-//   k_insb_diag_total (k_part2.hip)   literal diagonal sums of "arrangement, then the new scaffold" (OG:343)
 //   k_insb_base/_fast (k_part2_search.hip)  BASE / STRADDLE / CROSS terms of the 2(S+1) fast scores
-//   k_insb_shortlist      literal total (Python sum, serial); fast scores in the reference's enumeration
-//                         order; the candidates within 1e-9 of the best become the short list
-//   k_insb_diag_cand + k_insb_cost (k_part2.hip)  literal scores (NumPy's summation order) of the short list;
-//                         the candidates' bin orders are never materialised (IndexMap)
+//   k_insb_shortlist      fast scores in the reference's enumeration order; the candidates within 1e-9 of the
+//                         best become the short list.  ONE candidate (the usual case) is taken as it is: the
+//                         literal pass could not pick another, and only a job's final score is ever read
+//   k_insb_diag_cand + k_insb_cost (k_part2.hip)  the literal pass, for the chromosomes that still need it:
+//                         diagonal sums of "arrangement, then the new scaffold" (OG:343), their serial Python
+//                         sum (the step's total) and the literal scores (NumPy's summation order) of the short
+//                         list; the candidates' bin orders are never materialised (IndexMap)
 //   k_insb_apply          first strict maximum above 0. in enumeration order (OG:349,359) - or gap 0, '+' when
 //                         nothing scored above 0. (OG:341,367) - written to the log and applied to the
 //                         arrangement (ping-pong buffers).
@@ -25,7 +27,7 @@ namespace hicmi {
 __global__ void k_insb_reset(const InsStep* __restrict__ steps)
 {
     InsState* st = steps[blockIdx.x].st;
-    if (threadIdx.x == 0 && steps[blockIdx.x].active) { st->fail = -1; st->n_short = 0; }
+    if (threadIdx.x == 0 && steps[blockIdx.x].active) { st->fail = -1; st->n_short = 0; st->direct = 0; }
 }
 
 void launch_insb_reset(const InsStep* steps, int n_chrom, hipStream_t s)
@@ -34,44 +36,36 @@ void launch_insb_reset(const InsStep* steps, int n_chrom, hipStream_t s)
 }
 
 static constexpr int SL_THREADS = 256;
-static constexpr int SL_STAGE_MAX = 8192;              // doubles staged in LDS (64 KB)
 static constexpr int SL_LIST = 64;
 
-// The arithmetic (and its order) is that of hicmi_p2_score_insertions + hicmi_p2_decide_insertion on the
-// host, so both paths short-list the same candidates.
+// The fast scores are those of hicmi_p2_score_insertions without the division by the step's literal total - a
+// common positive factor, irrelevant to a ranking with a relative band - so the total (a full pass over the
+// sub-matrix plus a serial sum) is only formed for the steps that go on to the literal pass.
 __global__ __launch_bounds__(SL_THREADS) void k_insb_shortlist(const InsStep* __restrict__ steps, int n_base_blocks,
                                                                double near_top, int max_c)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sl[];
-    double* buf = reinterpret_cast<double*>(smem_sl);    // T staged for the serial total, then the STRADDLE prefix
-    __shared__ double s_total, s_base, s_wmax[SL_THREADS / 64];
+    double* buf = reinterpret_cast<double*>(smem_sl);    // the STRADDLE prefix
+    __shared__ double s_base, s_wmax[SL_THREADS / 64];
     __shared__ int s_any[SL_THREADS / 64], s_cnt, s_list[SL_LIST];
     const InsStep& d = steps[blockIdx.x];
     InsState* st = d.st;
     const int tid = threadIdx.x;
     if (!d.active || st->fail >= 0) return;
-    const int n_used = d.n_arr + d.L, S = d.S;
-    const double* __restrict__ T = d.T_total;
+    const int S = d.S;
     const double* __restrict__ partial = d.partial;
-    const bool staged = n_used <= SL_STAGE_MAX;
-    const int n_buf = (staged ? n_used : 0) > S + 1 ? (staged ? n_used : 0) : S + 1;
-    double* part = buf + n_buf;                          // BASE slabs and STRADDLE increments, staged
-    if (staged) for (int i = tid; i < n_used; i += SL_THREADS) buf[i] = T[i];
+    double* part = buf + S + 1;                          // BASE slabs and STRADDLE increments, staged
     for (int i = tid; i < n_base_blocks + S; i += SL_THREADS) part[i] = partial[i];
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     if (tid == 0) {
-        double acc = 0.0;                                // Python sum(): 0 + T_1 + T_2 + ...   (OG:343)
-        if (staged) acc = serial_sum_lds(buf, 1, n_used, 0.0);
-        else for (int i = 1; i < n_used; i++) acc += T[i];
-        s_total = acc;
         s_base = serial_sum_lds(part, 0, n_base_blocks, 0.0);
         buf[0] = 0.0;                                    // prefix[g] = increments 0..g-1, left to right
         for (int g = 0; g < S; g++) buf[g + 1] = part[n_base_blocks + g];
         serial_prefix_lds(buf, 1, S + 1, 0.0);
     }
     __syncthreads();
-    const double total = s_total, base = s_base;
+    const double base = s_base;
     const double* __restrict__ cross = partial + n_base_blocks + S;
     const int n_cand = 2 * (S + 1);
     // candidate i: gap i/2; the scaffold arrives '+', is tested as it is and then flipped, and stays flipped
@@ -79,7 +73,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_insb_shortlist(const InsStep* __
     auto fast_of = [&](int i) -> double {
         const int g = i >> 1, first = g & 1;
         const int r = (i & 1) ? (first ^ 1) : first;
-        return (base - buf[g] + cross[2 * g + r]) / total;
+        return base - buf[g] + cross[2 * g + r];
     };
     double mx = -__builtin_inf();
     int any = 0;
@@ -100,7 +94,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_insb_shortlist(const InsStep* __
     int have = 0;
     for (int w = 0; w < SL_THREADS / 64; w++) { if (s_wmax[w] > top) top = s_wmax[w]; have |= s_any[w]; }
     if (!have) {
-        if (tid == 0) { st->n_short = 0; st->total = total; }
+        if (tid == 0) { st->n_short = 0; st->direct = 0; }
         return;
     }
     const double thr = top - fabs(top) * near_top;
@@ -113,30 +107,45 @@ __global__ __launch_bounds__(SL_THREADS) void k_insb_shortlist(const InsStep* __
     }
     __syncthreads();
     if (tid == 0) {
-        const int cnt = s_cnt;
-        if (cnt > max_c) { st->fail = d.step; st->n_short = 0; return; }
+        int cnt = s_cnt;
+        st->direct = 0;
+        if (cnt > max_c && !(d.L == 1 && cnt <= 2 * max_c && cnt <= SL_LIST)) { st->fail = d.step; st->n_short = 0; return; }
         for (int a = 1; a < cnt; a++) {                  // enumeration order
             const int v = s_list[a];
             int b = a - 1;
             while (b >= 0 && s_list[b] > v) { s_list[b + 1] = s_list[b]; b--; }
             s_list[b + 1] = v;
         }
+        if (d.L == 1) {
+            // a one-bin scaffold reads the same in both orientations: the flipped twin of a listed candidate is the
+            // same bin order, scores the same literal value and comes second, so it can never be a strict maximum
+            int w = 0;
+            for (int q = 0; q < cnt; q++) {
+                const int i = s_list[q];
+                if ((i & 1) && w > 0 && s_list[w - 1] == i - 1) continue;
+                s_list[w++] = i;
+            }
+            cnt = w;
+            if (cnt > max_c) { st->fail = d.step; st->n_short = 0; return; }
+        }
         for (int q = 0; q < cnt; q++) {
             const int i = s_list[q], g = i >> 1, first = g & 1;
             st->idx[q] = i; st->gap[q] = g; st->rev[q] = (i & 1) ? (first ^ 1) : first;
         }
-        st->n_short = cnt;
-        st->total = total;
+        // One candidate within near_top of a positive best score: no other can overtake it in the literal
+        // arithmetic (the two agree to ~1e-13) and its literal score is positive like its fast one, so the
+        // literal pass is skipped - except at the job's final step, whose score is handed back (OG:493).
+        if (cnt == 1 && !d.last && top > 0.0) { st->direct = 1; st->n_short = 0; }
+        else st->n_short = cnt;
     }
 }
 
 static std::atomic<int> g_lds_shortlist{0};
 
-void launch_insb_shortlist(const InsStep* steps, int n_chrom, int max_n_used, int max_S, int n_base_blocks, double near_top,
-                           int max_c, hipStream_t s)
+void launch_insb_shortlist(const InsStep* steps, int n_chrom, int max_S, int n_base_blocks, double near_top, int max_c,
+                           hipStream_t s)
 {
-    const int t_part = max_n_used <= SL_STAGE_MAX ? max_n_used : SL_STAGE_MAX;   // a smaller chromosome may still stage
-    const int need = (t_part > max_S + 1 ? t_part : max_S + 1) + n_base_blocks + max_S;
+    const int need = (max_S + 1) + n_base_blocks + max_S;
     const size_t lds = (((size_t)need * sizeof(double)) + 15) & ~(size_t)15;
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_insb_shortlist), g_lds_shortlist, lds);
     hipLaunchKernelGGL(k_insb_shortlist, dim3(n_chrom), dim3(SL_THREADS), lds, s, steps, n_base_blocks, near_top,
@@ -153,8 +162,9 @@ __global__ __launch_bounds__(256) void k_insb_apply(const InsStep* __restrict__ 
     if ((int)blockIdx.x * 256 >= n_new && blockIdx.x != 0) return;
     double best = 0.0;
     int pick = -1;
-    const int ns = st->n_short;
+    const int ns = st->n_short, direct = st->direct;
     for (int q = 0; q < ns; q++) if (st->lit[q] > best) { best = st->lit[q]; pick = q; }   // first strict maximum
+    if (direct) { pick = 0; best = __builtin_nan(""); }   // not a final step: the value is never read
     const int gap = pick >= 0 ? st->gap[pick] : 0, rev = pick >= 0 ? st->rev[pick] : 0;
     const int32_t* __restrict__ id_in = d.packed_cur;
     const int32_t* __restrict__ pos_in = d.packed_cur + S;
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(256) void k_insb_apply(const InsStep* __restrict__ 
             rev_out[j] = j < gap ? rev_in[j] : (j == gap ? rev : rev_in[j - 1]);
         }
         for (int j = threadIdx.x; j <= S1; j += 256) pos_out[j] = j <= gap ? pos_in[j] : pos_in[j - 1] + L;
-        if (threadIdx.x == 0) { d.log->gap = gap; d.log->rev = rev; d.log->best = pick >= 0 ? best : 0.0; }
+        if (threadIdx.x == 0) { d.log->gap = gap; d.log->rev = rev; d.log->best = pick >= 0 ? best : 0.0; d.log->n_short = direct ? -1 : ns; }
     }
 }
 
