@@ -1313,7 +1313,7 @@ int queue_insertions(hicmi_ctx* lead, const std::vector<InsJob*>& jobs)
         if (rc) return rc;
         rc = ensure(c->d_ins_T, c->ins_t_cap, (1 + 2 * (int64_t)INS_MAXC) * n_max);
         if (rc) return rc;
-        rc = ensure(c->d_ins_partial, c->ins_partial_cap, NB + S_max + 2 * (S_max + 1));
+        rc = ensure(c->d_ins_partial, c->ins_partial_cap, NB + n_max + 2 * (S_max + 1));
         if (rc) return rc;
         steps_max = std::max(steps_max, n_steps);
         blob_off[(size_t)j] = blob_bytes;
@@ -1370,7 +1370,7 @@ int queue_insertions(hicmi_ctx* lead, const std::vector<InsJob*>& jobs)
             const InsStep* st_t = lead->d_ins_steps + t * nj;
             const int nu = max_n_used[(size_t)t];
             launch_insb_fast(st_t, nj, max_S[(size_t)t], max_n_arr[(size_t)t], NB, lead->stream);
-            launch_insb_shortlist(st_t, nj, max_S[(size_t)t], NB, kNearTop, max_c, lead->stream);
+            launch_insb_shortlist(st_t, nj, max_S[(size_t)t], max_n_arr[(size_t)t], NB, kNearTop, max_c, lead->stream);
             launch_insb_diag_cand(st_t, nj, nu, lead->stream);
             launch_insb_cost(st_t, nj, nu, lead->stream);
             launch_insb_apply(st_t, nj, nu, lead->stream);

@@ -207,8 +207,8 @@ struct InsStep {
 // k_part2.hip / k_part2_search.hip / k_part2_insert.hip: one launch serves all chromosomes (blockIdx.y)
 void launch_insb_reset(const InsStep* steps, int n_chrom, hipStream_t s);
 void launch_insb_fast(const InsStep* steps, int n_chrom, int max_S, int max_n_arr, int n_base_blocks, hipStream_t s);
-void launch_insb_shortlist(const InsStep* steps, int n_chrom, int max_S, int n_base_blocks, double near_top, int max_c,
-                           hipStream_t s);
+void launch_insb_shortlist(const InsStep* steps, int n_chrom, int max_S, int max_n_arr, int n_base_blocks, double near_top,
+                           int max_c, hipStream_t s);
 void launch_insb_diag_cand(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s);
 void launch_insb_cost(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s);
 void launch_insb_apply(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s);

@@ -37,6 +37,7 @@ void launch_insb_reset(const InsStep* steps, int n_chrom, hipStream_t s)
 
 static constexpr int SL_THREADS = 256;
 static constexpr int SL_LIST = 64;
+static constexpr int SL_STAGE_MAX = 8192;              // STRADDLE row values staged in LDS (64 KB); longer: read from L2
 
 // The fast scores are those of hicmi_p2_score_insertions without the division by the step's literal total - a
 // common positive factor, irrelevant to a ranking with a relative band - so the total (a full pass over the
@@ -52,21 +53,32 @@ __global__ __launch_bounds__(SL_THREADS) void k_insb_shortlist(const InsStep* __
     InsState* st = d.st;
     const int tid = threadIdx.x;
     if (!d.active || st->fail >= 0) return;
-    const int S = d.S;
+    const int S = d.S, n_arr = d.n_arr;
     const double* __restrict__ partial = d.partial;
-    double* part = buf + S + 1;                          // BASE slabs and STRADDLE increments, staged
-    for (int i = tid; i < n_base_blocks + S; i += SL_THREADS) part[i] = partial[i];
+    const int32_t* __restrict__ arr_pos = d.packed_cur + S;
+    double* part = buf + S + 1;                          // BASE slabs, then the STRADDLE row values s(u), staged
+    const bool staged = n_arr <= SL_STAGE_MAX;
+    const int n_stage = n_base_blocks + (staged ? n_arr : 0);
+    for (int i = tid; i < n_stage; i += SL_THREADS) part[i] = partial[i];
     if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    // STRADDLE(g+1) - STRADDLE(g): the rows of scaffold g, added in position order (one lane per scaffold)
+    for (int g = tid; g < S; g += SL_THREADS) {
+        const int P0 = arr_pos[g], P1 = arr_pos[g + 1];
+        double acc = 0.0;
+        if (staged) for (int u = P0; u < P1; u++) acc += part[n_base_blocks + u];
+        else for (int u = P0; u < P1; u++) acc += partial[n_base_blocks + u];
+        buf[g + 1] = acc;
+    }
     __syncthreads();
     if (tid == 0) {
         s_base = serial_sum_lds(part, 0, n_base_blocks, 0.0);
         buf[0] = 0.0;                                    // prefix[g] = increments 0..g-1, left to right
-        for (int g = 0; g < S; g++) buf[g + 1] = part[n_base_blocks + g];
         serial_prefix_lds(buf, 1, S + 1, 0.0);
     }
     __syncthreads();
     const double base = s_base;
-    const double* __restrict__ cross = partial + n_base_blocks + S;
+    const double* __restrict__ cross = partial + n_base_blocks + n_arr;
     const int n_cand = 2 * (S + 1);
     // candidate i: gap i/2; the scaffold arrives '+', is tested as it is and then flipped, and stays flipped
     // for the next gap (OG:344-365), so gap g tests orientation g&1 first
@@ -142,10 +154,10 @@ __global__ __launch_bounds__(SL_THREADS) void k_insb_shortlist(const InsStep* __
 
 static std::atomic<int> g_lds_shortlist{0};
 
-void launch_insb_shortlist(const InsStep* steps, int n_chrom, int max_S, int n_base_blocks, double near_top, int max_c,
-                           hipStream_t s)
+void launch_insb_shortlist(const InsStep* steps, int n_chrom, int max_S, int max_n_arr, int n_base_blocks, double near_top,
+                           int max_c, hipStream_t s)
 {
-    const int need = (max_S + 1) + n_base_blocks + max_S;
+    const int need = (max_S + 1) + n_base_blocks + (max_n_arr < SL_STAGE_MAX ? max_n_arr : SL_STAGE_MAX);
     const size_t lds = (((size_t)need * sizeof(double)) + 15) & ~(size_t)15;
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_insb_shortlist), g_lds_shortlist, lds);
     hipLaunchKernelGGL(k_insb_shortlist, dim3(n_chrom), dim3(SL_THREADS), lds, s, steps, n_base_blocks, near_top,

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_p2_base_partial(const double* __restric
     base_partial_body(M2, ld2, p, n_arr, H, n_tot, blockIdx.x, gridDim.x, partial + blockIdx.x);
 }
 
-static std::atomic<int> g_lds_base{0}, g_lds_straddle{0}, g_lds_cross{0}, g_lds_wdelta{0}, g_lds_wdelta1{0}, g_lds_wdelta_blk{0}, g_lds_wG{0}, g_lds_insb_base{0}, g_lds_insb_fast{0};
+static std::atomic<int> g_lds_base{0}, g_lds_straddle{0}, g_lds_cross{0}, g_lds_wdelta{0}, g_lds_wdelta1{0}, g_lds_wdelta_blk{0}, g_lds_wG{0}, g_lds_insb_base{0};
 
 // BASE as partial sums over row slabs: out[0..n_blocks)
 void launch_p2_base_partial(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const double* H, int n_tot,
@@ -224,7 +224,6 @@ void launch_p2_insert_delta(const double* M2, int64_t ld2, const int32_t* pos2se
 }
 
 // ---- lock-step insertion (k_part2_insert.hip): one layer of workgroups per chromosome --------------
-// partial layout per chromosome: [n_base_blocks BASE slabs][S STRADDLE increments][2(S+1) CROSS terms]
 __global__ __launch_bounds__(256) void k_insb_base(const InsStep* __restrict__ steps, int n_base_blocks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -236,34 +235,79 @@ __global__ __launch_bounds__(256) void k_insb_base(const InsStep* __restrict__ s
     base_partial_body(d.M2, d.ld2, p, d.n_arr, d.H, d.n_arr + d.L, blockIdx.x, n_base_blocks, d.partial + blockIdx.x);
 }
 
-// workgroups [0, S): STRADDLE increments; [S, S + 2(S+1)): CROSS terms
-__global__ __launch_bounds__(1024) void k_insb_fast(const InsStep* __restrict__ steps, int n_base_blocks)
+// Lock-step form of STRADDLE and CROSS, one WAVE per matrix row so that short scaffolds do not leave most of a
+// large workgroup idle (a late insertion has L = 1..3 bins and the 16-wave bodies above kept 1..3 waves busy):
+//   workgroups [0, ceil(n_arr / 4)): wave = arrangement position u.  With its scaffold spanning [P0, P1),
+//       s(u) = - sum_{pos < P0} M[u][pos] dw(u - pos) + sum_{pos >= P1} M[u][pos] dw(pos - u),
+//       dw(d) = H[d + L - 1] - H[d - 1];   STRADDLE(g+1) - STRADDLE(g) = sum of s(u) over scaffold g
+//       (k_insb_shortlist adds the rows of a scaffold in position order)
+//   workgroups after those: one per (gap, orientation), CROSS as in cross_body with 4 waves over the new bins.
+// partial layout per chromosome: [n_base_blocks BASE slabs][n_arr row values s(u)][2(S+1) CROSS terms]
+__global__ __launch_bounds__(256) void k_insb_fast(const InsStep* __restrict__ steps, int n_base_blocks, int n_row_blocks)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int32_t* p = reinterpret_cast<int32_t*>(smem);
-    __shared__ double s_w[16];
+    __shared__ double s_w[4];
     const InsStep& d = steps[blockIdx.y];
     if (!d.active || d.st->fail >= 0) return;
-    const int b = blockIdx.x, S = d.S;
-    if (b >= S + 2 * (S + 1)) return;
-    for (int q = threadIdx.x; q < d.n_arr; q += 1024) p[q] = d.pos_cur[q];
-    __syncthreads();
+    const int S = d.S, n_arr = d.n_arr, L = d.L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t* __restrict__ p = d.pos_cur;
     const int32_t* __restrict__ arr_pos = d.packed_cur + S;
-    if (b < S) straddle_body(d.M2, d.ld2, p, d.n_arr, arr_pos, b, d.L, d.H, s_w, d.partial + n_base_blocks + b);
-    else {
-        const int c = b - S;
-        cross_body(d.M2, d.ld2, p, d.n_arr, arr_pos, c >> 1, c & 1, d.new_start, d.L, d.H, s_w,
-                   d.partial + n_base_blocks + S + c);
+    const double* __restrict__ H = d.H;
+    if ((int)blockIdx.x < n_row_blocks) {
+        const int u = blockIdx.x * 4 + wave;
+        if (u >= n_arr) return;
+        int below = 0;                                    // scaffold of position u: the last gap with arr_pos <= u
+        for (int j = lane; j <= S; j += 64) below += arr_pos[j] <= u;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) below += __shfl_xor(below, off, 64);
+        const int g = below - 1;
+        const int P0 = arr_pos[g], P1 = arr_pos[g + 1];
+        const double* __restrict__ row = d.M2 + (int64_t)p[u] * d.ld2;
+        double acc = 0.0;
+#pragma unroll 4
+        for (int pos = lane; pos < P0; pos += 64) {
+            const int dd = u - pos;
+            acc -= row[p[pos]] * (H[dd + L - 1] - H[dd - 1]);
+        }
+#pragma unroll 4
+        for (int pos = P1 + lane; pos < n_arr; pos += 64) {
+            const int dd = pos - u;
+            acc += row[p[pos]] * (H[dd + L - 1] - H[dd - 1]);
+        }
+        acc = wave_sum_s(acc);
+        if (lane == 0) d.partial[n_base_blocks + u] = acc;
+        return;
     }
+    const int c = blockIdx.x - n_row_blocks;
+    if (c >= 2 * (S + 1)) return;
+    const int g = c >> 1, r = c & 1, P = arr_pos[g];
+    const double hn = H[n_arr + L - 1];
+    double acc = 0.0;
+    for (int e = wave; e < L; e += 4) {
+        const int xe = d.new_start + (r ? L - 1 - e : e);
+        const double* __restrict__ row = d.M2 + (int64_t)xe * d.ld2;
+#pragma unroll 4
+        for (int q = lane; q < n_arr; q += 64) {
+            const int dd = q < P ? (P + e - q) : (q + L - (P + e));
+            acc += row[p[q]] * (hn - H[dd - 1]);
+        }
+        for (int e2 = e + 1 + lane; e2 < L; e2 += 64) {
+            const int x2 = d.new_start + (r ? L - 1 - e2 : e2);
+            acc += row[x2] * (hn - H[e2 - e - 1]);
+        }
+    }
+    const double sum = block_sum_256(acc, s_w);
+    if (threadIdx.x == 0) d.partial[n_base_blocks + n_arr + c] = sum;
 }
 
 void launch_insb_fast(const InsStep* steps, int n_chrom, int max_S, int max_n_arr, int n_base_blocks, hipStream_t s)
 {
     const size_t lds = perm_lds_bytes(max_n_arr);
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_insb_base), g_lds_insb_base, lds);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_insb_fast), g_lds_insb_fast, lds);
     hipLaunchKernelGGL(k_insb_base, dim3(n_base_blocks, n_chrom), dim3(256), lds, s, steps, n_base_blocks);
-    hipLaunchKernelGGL(k_insb_fast, dim3(max_S + 2 * (max_S + 1), n_chrom), dim3(1024), lds, s, steps, n_base_blocks);
+    const int n_row_blocks = (max_n_arr + 3) / 4;
+    hipLaunchKernelGGL(k_insb_fast, dim3(n_row_blocks + 2 * (max_S + 1), n_chrom), dim3(256), 0, s, steps, n_base_blocks,
+                       n_row_blocks);
 }
 
 // ---- window: G table ----------------------------------------------------------------------------
