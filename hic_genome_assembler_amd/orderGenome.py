@@ -207,14 +207,22 @@ def readChromsFromFile(inFile):
     chroms, cur = [], []
     with open(inFile) as fh:
         fh.readline()
-        for line in fh:
-            line = line.strip("\r").strip("\n")
-            if line[0] != "#":
-                cols = line.split("\t")
-                cur.append([int(cols[0]), cols[1]])
-            else:
-                chroms.append(cur)
-                cur = []
+        text = fh.read()
+    if "\r" in text:                                   # rare: keep the reference's exact stripping (OG:222)
+        lines = [ln.strip("\r").strip("\n") for ln in text.splitlines(keepends=True)]
+    else:
+        lines = text.split("\n")
+        if lines and lines[-1] == "":                   # the file's final newline
+            lines.pop()
+    add = cur.append
+    for line in lines:
+        if line[0] != "#":
+            cols = line.split("\t", 2)
+            add([int(cols[0]), cols[1]])
+        else:
+            chroms.append(cur)
+            cur = []
+            add = cur.append
     chroms.append(cur)
     print("Chromosomes found " + str(len(chroms)))
     print("Nodes found " + str(sum(len(c) for c in chroms)))
@@ -783,14 +791,13 @@ def writeScaffoldOrderingsToFile(sOrderings, outFile):
 
 def writeBinIDsOrderingToFile(scaffoldList, outFile):
     """OG:646-660: header line, then newline-PREFIXED rows (no trailing newline)."""
-    written = 0
+    rows = ["#ScaffoldID\tHiCPro-BinID"]
+    for s in scaffoldList:
+        head = "\n" + s.name + "\t"
+        rows.extend([head + str(b) for b in s.binList])
     with open(outFile, "w") as fh:
-        fh.write("#ScaffoldID\tHiCPro-BinID")
-        for s in scaffoldList:
-            for b in s.binList:
-                fh.write("\n" + s.name + "\t" + str(b))
-                written += 1
-    print("BinIDs written to file " + str(written))
+        fh.write("".join(rows))
+    print("BinIDs written to file " + str(len(rows) - 1))
 
 
 def getChromosomeOutlineCoords(orderedChromosomes):

@@ -229,3 +229,33 @@ def test_matrix_binary_cache(tmp_path):
         fh.write("%d\t%d\t7.5\n" % (bins[1].ID, bins[2].ID))
     fresh = hostio.read_contact_matrix_cached(paths["matrix"], bins[1:], str(cache_dir))
     assert fresh[0, 1] == 7.5 and fresh[1, 0] == 7.5
+
+
+def test_read_chroms_line_handling(tmp_path):
+    """OG:216-237 line by line (strip "\\r" then "\\n", '#' lines open a group) against the bulk reader."""
+    import contextlib
+    import io
+    from hic_genome_assembler_amd import orderGenome as og
+
+    def literal(path):
+        chroms, cur = [], []
+        with open(path) as fh:
+            fh.readline()
+            for line in fh:
+                line = line.strip("\r").strip("\n")
+                if line[0] != "#":
+                    cols = line.split("\t")
+                    cur.append([int(cols[0]), cols[1]])
+                else:
+                    chroms.append(cur)
+                    cur = []
+        chroms.append(cur)
+        return chroms
+    texts = ["### g1 ###\n1\ta\tx\n2\tb\ty\n### g2 ###\n3\tc\tz\n", "### g1 ###\n1\ta\tx\n2\tb",
+             "### g1 ###\r\n1\ta\tx\r\n### g2 ###\r\n3\tc\r\n", "### g1 ###\n"]
+    for k, text in enumerate(texts):
+        path = tmp_path / ("g%d.txt" % k)
+        with open(path, "w", newline="") as fh:
+            fh.write(text)
+        with contextlib.redirect_stdout(io.StringIO()):
+            assert og.readChromsFromFile(str(path)) == literal(str(path)), text
