@@ -72,8 +72,8 @@ def cpu_baseline(sample_bins, n_scaffolds, scan_scaffolds, work):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bins", type=int, default=16000)
     ap.add_argument("--n-scaffolds", type=int, default=6)
     ap.add_argument("--scan-scaffolds", type=int, default=5)
