@@ -516,7 +516,7 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         free_dev(c->d_size); free_dev(c->d_chain); free_dev(c->d_zraw); free_dev(c->d_status);
         c->d_size = c->d_chain = c->d_status = nullptr; c->d_zraw = nullptr;
         HIPCHK(hipMalloc((void**)&c->d_size, nnchain_workspace_bytes((int)n)));
-        HIPCHK(hipMalloc((void**)&c->d_chain, sizeof(int) * (size_t)(n + 2)));
+        HIPCHK(hipMalloc((void**)&c->d_chain, sizeof(int) * 8 * (size_t)(n + 2)));      // one copy per workgroup of k_nn_epoch_mw
         HIPCHK(hipMalloc((void**)&c->d_zraw, sizeof(double) * 4 * (size_t)n));
         HIPCHK(hipMalloc((void**)&c->d_status, sizeof(int)));
     }

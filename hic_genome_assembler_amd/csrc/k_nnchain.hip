@@ -27,6 +27,7 @@ namespace hicmi {
 
 static constexpr int NN_THREADS = 1024;
 static constexpr int NN_DMAX = 1024;                     // at most one dirty entry per lane
+static constexpr int NN_MAXWG = 8;                       // workgroups of the column-sliced chain (k_nn_epoch_mw)
 
 struct ArgMin { double v; int i; };
 
@@ -92,6 +93,7 @@ __device__ __forceinline__ ArgMin argmin_wave(ArgMin a)
 struct NNWorkspace {
     int* state;                 // [0] step [1] len [2] top [3] second [4] first_ptr [5] stop [6] n_dirty
     unsigned long long* prof;   // 6 phase totals
+    void* mail;                 // k_nn_epoch_mw: 2 x NN_MAXWG 16-byte mailbox slots
     uint32_t* alive;            // nwords
     uint16_t* size;             // n
     int* gtime;                 // n: dirty time stamp of a slot in the finished epoch, -1 = clean
@@ -107,7 +109,7 @@ static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 size_t nnchain_workspace_bytes(int n)
 {
     size_t nwords = (size_t)(n + 31) / 32;
-    return 256 + align16(nwords * 4) + align16((size_t)n * 2) + 4 * align16((size_t)n * 4) + 2 * align16(NN_DMAX * 4);
+    return 512 + align16(nwords * 4) + align16((size_t)n * 2) + 4 * align16((size_t)n * 4) + 2 * align16(NN_DMAX * 4);
 }
 
 static NNWorkspace carve(void* ws, int n)
@@ -117,7 +119,8 @@ static NNWorkspace carve(void* ws, int n)
     NNWorkspace w;
     w.state = reinterpret_cast<int*>(p);
     w.prof = reinterpret_cast<unsigned long long*>(p + 64);
-    p += 256;
+    w.mail = p + 256;
+    p += 512;
     w.alive = reinterpret_cast<uint32_t*>(p); p += align16(nwords * 4);
     w.size = reinterpret_cast<uint16_t*>(p); p += align16((size_t)n * 2);
     w.gtime = reinterpret_cast<int*>(p); p += align16((size_t)n * 4);
@@ -329,6 +332,356 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
     }
 }
 
+// ---- the same chain on several workgroups (k_nn_epoch_mw) -----------------------------------------------
+// A lone CU streams a row at ~77 GB/s: at 16k bins a 128 KB scan is two thirds transfer, one third latency.
+// Here NWG workgroups (one CU each, any XCD) run the SAME chain as replicated state machines: each keeps the
+// full LDS state (liveness, sizes, dirty list, chain) and takes every decision itself, but streams only ITS
+// SLICE of the columns of a row - in scans and in Lance-Williams updates.  The one thing a decision needs from
+// the others is their slice's (min, index): ONE exchange per scan through 16-byte mailbox slots
+// {value, index, sequence number} written and polled with sc1 (write-through / L1-bypassing) accesses, no
+// fences (MI355X_MICROARCH.md, "Valid forms": sc1 stores, every storing wave drained behind a workgroup
+// barrier, one lane signals, the polling wave loads after its poll, the others after a barrier).  Slots are
+// double-buffered by the parity of the sequence number: a workgroup can be at most one exchange ahead.
+// Visibility of matrix bytes: a workgroup plainly loads only columns of its own slice, which only it ever
+// writes (sc1 stores); every element that may lie in another slice - dirty partners' W[d][x], d(x, prev) - is
+// read with an sc1 load, and was written before the writer's previous exchange.  The single element that is
+// needed BEFORE an exchange has happened - W[y'][z] for the cluster y' merged a moment ago and the row z the
+// next scan visits - is handed from the owner of column z (which computes it in its update) to the owner of
+// column y' (the only reader: it lists y' among its dirty candidates) through a tagged 16-byte slot of its own.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16_sc1(void* p, u32x4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ u32x4 ld16_sc1(const void* p)
+{
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ double ld8_sc1(const double* p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st8_sc1(double* p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Streaming loads of the workgroup's own slice are sc1 too: plain (and nontemporal) re-loads of a line this
+// workgroup had itself rewritten with sc1 stores returned pre-update values now and then (observed on gfx950;
+// with every load sc1 the chain is bit-exact and repeatable).  Issued in pairs from inline assembly - the
+// compiler's wait-count pass does not see them - and drained by one s_waitcnt that also "produces" the registers,
+// so no use can be scheduled ahead of it.
+#define NN_LD16_SC1(reg, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(reg) : "v"(ptr) : "memory")
+#define NN_DRAIN2(a, b) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory")
+#define NN_DRAIN4(a, b, c, d) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory")
+__device__ __forceinline__ double2 mw_pair(u32x4 r)
+{
+    double2 v;
+    v.x = __hiloint2double((int)r.y, (int)r.x); v.y = __hiloint2double((int)r.w, (int)r.z);
+    return v;
+}
+
+// A 16-byte sc1 store may land as two 8-byte halves, so each half carries the sequence number itself:
+//   {value bits 31..0, seq} {value bits 63..32, index | (seq & 0x7fff) << 17}     (index < 2^17; 0x1ffff = none)
+__device__ __forceinline__ u32x4 mw_pack(double v, int idx, unsigned int seq)
+{
+    u32x4 p;
+    p.x = (unsigned int)__double2loint(v); p.y = seq;
+    p.z = (unsigned int)__double2hiint(v);
+    p.w = ((unsigned int)(idx < 0x1ffff ? idx : 0x1ffff)) | ((seq & 0x7fffu) << 17);
+    return p;
+}
+__device__ __forceinline__ bool mw_ready(u32x4 p, unsigned int seq) { return p.y == seq && (p.w >> 17) == (seq & 0x7fffu); }
+__device__ __forceinline__ double mw_value(u32x4 p) { return __hiloint2double((int)p.z, (int)p.x); }
+__device__ __forceinline__ int mw_index(u32x4 p) { const int i = (int)(p.w & 0x1ffffu); return i == 0x1ffff ? 0x7fffffff : i; }
+
+template <int NWG>
+__global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__ W, int64_t ld, int n,
+                                                            int* __restrict__ chain_all, double* __restrict__ zraw,
+                                                            NNWorkspace w, int dcap, int total_steps)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_nn[];
+    const int nwords = (n + 31) >> 5, nw4 = (nwords + 3) & ~3;
+    uint32_t* alive = reinterpret_cast<uint32_t*>(smem_nn);
+    uint32_t* smask = alive + nw4;
+    uint16_t* lsize = reinterpret_cast<uint16_t*>(smask + nw4);
+    __shared__ int dslot[NN_DMAX], dtime[NN_DMAX];
+    __shared__ double s_v[16];
+    __shared__ int s_i[16];
+    __shared__ int ring[256];
+    __shared__ double s_dprev, s_fresh;
+    __shared__ int s_x, s_prev, s_done, s_stop, s_mx, s_my, s_nx, s_ny, s_tx, s_ty, s_ey, s_nextx, s_fresh_x, s_fresh_y, s_fresh_tag,
+        s_fresh_local, s_late;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
+    int* __restrict__ chain = chain_all + (int64_t)wg * (n + 2);           // every workgroup keeps its own copy
+    u32x4* mail = reinterpret_cast<u32x4*>(w.mail);
+    u32x4* fresh_slot = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(w.state) + 128);
+    int step = w.state[0];
+    if (step >= total_steps || w.state[5]) {
+        if (tid == 0 && wg == 0) w.state[6] = 0;
+        return;
+    }
+    // column slice of this workgroup: multiples of 64 so that mask words and 16-byte loads never straddle
+    const int slice = (((n + NWG - 1) / NWG) + 63) & ~63;
+    const int c0 = wg * slice < n ? wg * slice : n;
+    const int c1 = c0 + slice < n ? c0 + slice : n;
+    for (int i = tid; i < nwords; i += NN_THREADS) { alive[i] = w.alive[i]; smask[i] = w.alive[i]; }
+    for (int i = tid; i < n; i += NN_THREADS) lsize[i] = w.size[i];
+    int len = w.state[1], top = w.state[2], second = w.state[3], first_ptr = w.state[4], ring_lo = len;
+    if (tid == 0) { s_stop = 0; s_done = 0; s_fresh_x = -1; s_fresh_y = -1; s_fresh_tag = 0; s_fresh_local = 0; s_late = 0; }
+    // the chain prefix of the earlier epochs (saved by workgroup 0) is read from workgroup 0's copy
+    const int* __restrict__ chain0 = chain_all;
+    __syncthreads();
+    int D = 0;
+    uint32_t xbit = 0u;
+    unsigned int xseq = 0u;                                  // exchanges so far (uniform)
+    int lowmark = len;                                       // lane 0: chain entries below this are still the earlier epochs'
+
+    for (; step < total_steps && D < dcap; step++) {
+        if (tid == 0 && len == 0) {
+            while (first_ptr < n && !((alive[first_ptr >> 5] >> (first_ptr & 31)) & 1u)) first_ptr++;
+            chain[0] = first_ptr; ring[0] = first_ptr; ring_lo = 0; top = first_ptr; second = -1; len = 1;
+        }
+        int guard = 0;
+        double cur = 0.0;
+        int ybest = -1;
+        while (true) {
+            if (tid == 0) {
+                s_x = top; s_prev = (len > 1) ? second : -1; s_tx = -1;
+                xbit = smask[top >> 5] & (1u << (top & 31));
+                smask[top >> 5] &= ~xbit;
+            }
+            __syncthreads();
+            const int x = s_x, prev = s_prev;
+            if (tid < D && dslot[tid] == x) s_tx = dtime[tid];
+            __syncthreads();
+            const int tx = s_tx;
+            const double* __restrict__ rowx = W + (int64_t)x * ld;
+            const bool use_fresh = (s_fresh_x == x);
+            const int fresh_y = s_fresh_y;
+            if (tid == 64 && prev >= 0 && ((smask[prev >> 5] >> (prev & 31)) & 1u)) s_dprev = ld8_sc1(rowx + prev);
+            ArgMin cand = {__builtin_inf(), 0x7fffffff};
+            if (tid < D) {
+                const int d = dslot[tid];
+                if (d >= 0 && d != x && ((alive[d >> 5] >> (d & 31)) & 1u)) {
+                    const bool mine = d >= c0 && d < c1;
+                    if (mine || d == prev) {
+                        double v;
+                        if (use_fresh && d == fresh_y) {                     // merged a moment ago: no exchange since
+                            if (s_fresh_local) v = s_fresh;
+                            else {
+                                const unsigned int tag = (unsigned int)s_fresh_tag;
+                                u32x4 r = ld16_sc1(fresh_slot);
+                                int budget = 1000000;
+                                while (!mw_ready(r, tag) && --budget > 0) { __builtin_amdgcn_s_sleep(1); r = ld16_sc1(fresh_slot); }
+                                if (!mw_ready(r, tag)) s_late = 1;
+                                v = mw_value(r);
+                            }
+                        }
+                        else v = dtime[tid] > tx ? ld8_sc1(W + (int64_t)d * ld + x) : ld8_sc1(rowx + d);
+                        if (mine) { cand.v = v; cand.i = d; }
+                        if (d == prev) s_dprev = v;
+                    }
+                }
+            }
+            ArgMin best = {__builtin_inf(), 0x7fffffff};
+            for (int j0 = c0 + tid * 2; j0 < c1; j0 += 4 * NN_THREADS) {    // two 16-byte loads in flight per lane
+                const int j1 = j0 + 2 * NN_THREADS;
+                const bool two = j1 < c1;
+                u32x4 r0, r1;
+                NN_LD16_SC1(r0, rowx + j0);
+                NN_LD16_SC1(r1, rowx + (two ? j1 : j0));
+                NN_DRAIN2(r0, r1);
+                {
+                    const double2 v = mw_pair(r0);
+                    const uint32_t bits = smask[j0 >> 5] >> (j0 & 31);
+                    if ((bits & 1u) && v.x < best.v) { best.v = v.x; best.i = j0; }
+                    if ((bits & 2u) && v.y < best.v) { best.v = v.y; best.i = j0 + 1; }
+                }
+                if (two) {
+                    const double2 v = mw_pair(r1);
+                    const uint32_t bits = smask[j1 >> 5] >> (j1 & 31);
+                    if ((bits & 1u) && v.x < best.v) { best.v = v.x; best.i = j1; }
+                    if ((bits & 2u) && v.y < best.v) { best.v = v.y; best.i = j1 + 1; }
+                }
+            }
+            if (cand.v < best.v || (cand.v == best.v && cand.i < best.i)) best = cand;
+            best = argmin_wave(best);
+            if (lane == 0) { s_v[wave] = best.v; s_i[wave] = best.i; }
+            __syncthreads();
+            xseq++;
+            if (wave == 0) {
+                ArgMin m = {lane < 16 ? s_v[lane] : __builtin_inf(), lane < 16 ? s_i[lane] : 0x7fffffff};
+                m = argmin_row16(m);                                // this slice's result, in every lane of row 0
+                u32x4* slots = mail + (xseq & 1u) * NN_MAXWG;
+                if (lane == 0) st16_sc1(slots + wg, mw_pack(m.v, m.i, xseq));
+                ArgMin o = {__builtin_inf(), 0x7fffffff};
+                int late = 0;
+                if (lane < NWG) {
+                    if (lane == wg) o = m;
+                    else {
+                        u32x4 r = ld16_sc1(slots + lane);
+                        int budget = 1000000;
+                        while (!mw_ready(r, xseq) && --budget > 0) { __builtin_amdgcn_s_sleep(1); r = ld16_sc1(slots + lane); }
+                        if (!mw_ready(r, xseq)) late = 1;
+                        o.v = mw_value(r); o.i = mw_index(r);
+                    }
+                }
+                late = __any(late);
+                m = argmin_row16(o);
+                if (lane == 0) {
+                    int y; double c;
+                    if (prev >= 0) {
+                        double dprev = s_dprev;
+                        if (m.v < dprev) { y = m.i; c = m.v; } else { y = prev; c = dprev; }
+                    } else { y = m.i; c = m.v; }
+                    int done = (prev >= 0 && y == prev);
+                    if (late || s_late || y < 0 || y >= n || ++guard > n + 2) { s_stop = 1; done = 1; }
+                    else if (!done) {
+                        chain[len] = y; ring[len & 255] = y;
+                        if (len - 255 > ring_lo) ring_lo = len - 255;
+                        second = top; top = y; len++;
+                    }
+                    cur = c; ybest = y;
+                    smask[x >> 5] |= xbit;
+                    s_done = done;
+                    s_fresh_x = -1;                                 // an exchange has happened: memory is current
+                }
+            }
+            __syncthreads();
+            if (s_done) break;
+        }
+        if (s_stop) break;
+        if (tid == 0) {
+            int xx = s_x, yy = ybest;
+            len -= 2;
+            if (xx > yy) { int t = xx; xx = yy; yy = t; }
+            int nx = lsize[xx], ny = lsize[yy];
+            if (wg == 0) {
+                zraw[4 * (int64_t)step + 0] = (double)xx;
+                zraw[4 * (int64_t)step + 1] = (double)yy;
+                zraw[4 * (int64_t)step + 2] = cur;
+                zraw[4 * (int64_t)step + 3] = (double)(nx + ny);
+            }
+            lsize[xx] = 0;
+            lsize[yy] = (uint16_t)(nx + ny);
+            alive[xx >> 5] &= ~(1u << (xx & 31));
+            smask[xx >> 5] &= ~(1u << (xx & 31));
+            s_mx = xx; s_my = yy; s_nx = nx; s_ny = ny; s_tx = -1; s_ty = -1; s_ey = -1;
+            // entries no push of this epoch has overwritten live in workgroup 0's copy (saved by the last epoch)
+            if (len < lowmark) lowmark = len;
+            const int i1 = len - 1, i2 = len - 2;
+            top = len >= 1 ? (i1 >= ring_lo ? ring[i1 & 255] : (i1 < lowmark ? chain0[i1] : chain[i1])) : -1;
+            second = len >= 2 ? (i2 >= ring_lo ? ring[i2 & 255] : (i2 < lowmark ? chain0[i2] : chain[i2])) : -1;
+            // the row the next scan visits (its d(., y') is needed before any exchange)
+            int nextx = top;
+            if (len == 0) {
+                int fp = first_ptr;
+                while (fp < n && !((alive[fp >> 5] >> (fp & 31)) & 1u)) fp++;
+                nextx = fp < n ? fp : -1;
+            }
+            s_nextx = nextx;
+        }
+        __syncthreads();
+        const int mx = s_mx, my = s_my;
+        if (tid < D) {
+            if (dslot[tid] == mx) s_tx = dtime[tid];
+            if (dslot[tid] == my) { s_ty = dtime[tid]; s_ey = tid; }
+        }
+        __syncthreads();
+        {
+            const int tmx = s_tx, tmy = s_ty, nextx = s_nextx;
+            const double fx = (double)s_nx, fy = (double)s_ny, fs = (double)(s_nx + s_ny);
+            const double rcp = 1.0 / fs;
+            const double* __restrict__ rx = W + (int64_t)mx * ld;
+            double* __restrict__ ry = W + (int64_t)my * ld;
+            double dv = 0.0; int dd = -1;
+            double fresh_out = __builtin_nan("");              // the owner of column nextx hands W[y'][nextx] on
+            bool have_fresh = false;
+            if (tid < D) {
+                const int d = dslot[tid];
+                if (d >= 0 && d != my && ((alive[d >> 5] >> (d & 31)) & 1u)) {
+                    if (d >= c0 && d < c1) {                          // columns of this slice only: rx[d], ry[d] are its own
+                        const double dxi = dtime[tid] > tmx ? ld8_sc1(W + (int64_t)d * ld + mx) : ld8_sc1(rx + d);
+                        const double dyi = dtime[tid] > tmy ? ld8_sc1(W + (int64_t)d * ld + my) : ld8_sc1(ry + d);
+                        dv = div_by_small_int(fx * dxi + fy * dyi, fs, rcp);
+                        dd = d;
+                        if (d == nextx) { fresh_out = dv; have_fresh = true; }
+                    }
+                }
+            }
+            for (int j0 = c0 + tid * 2; j0 < c1; j0 += 4 * NN_THREADS) {
+                const int j1 = j0 + 2 * NN_THREADS;
+                const bool two = j1 < c1;
+                u32x4 ra0, rb0, ra1, rb1;
+                NN_LD16_SC1(ra0, rx + j0);
+                NN_LD16_SC1(rb0, ry + j0);
+                NN_LD16_SC1(ra1, rx + (two ? j1 : j0));
+                NN_LD16_SC1(rb1, ry + (two ? j1 : j0));
+                NN_DRAIN4(ra0, rb0, ra1, rb1);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if (h == 1 && !two) break;
+                    const int j = h ? j1 : j0;
+                    const double2 a = mw_pair(h ? ra1 : ra0);
+                    double2 b = mw_pair(h ? rb1 : rb0);
+                    const uint32_t bits = smask[j >> 5] >> (j & 31);
+                    if ((bits & 1u) && j != my) b.x = div_by_small_int(fx * a.x + fy * b.x, fs, rcp);
+                    if ((bits & 2u) && j + 1 != my) b.y = div_by_small_int(fx * a.y + fy * b.y, fs, rcp);
+                    if (j == nextx && (bits & 1u)) { fresh_out = b.x; have_fresh = true; }
+                    if (j + 1 == nextx && (bits & 2u)) { fresh_out = b.y; have_fresh = true; }
+                    u32x4 pk;
+                    pk.x = (unsigned int)__double2loint(b.x); pk.y = (unsigned int)__double2hiint(b.x);
+                    pk.z = (unsigned int)__double2loint(b.y); pk.w = (unsigned int)__double2hiint(b.y);
+                    st16_sc1(ry + j, pk);
+                }
+            }
+            if (have_fresh && nextx != my) {
+                st16_sc1(fresh_slot, mw_pack(fresh_out, 0, (unsigned int)(step + 1)));
+                s_fresh = fresh_out;
+            }
+            // the pair stores above are inline assembly the compiler's wait-count pass does not see: drain them before
+            // the barrier, or a dirty column's 8-byte store below could be overtaken by the pair store that still
+            // carries its old value
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (dd >= 0) st8_sc1(ry + dd, dv);
+            if (tid == 0) {
+                if (s_ey >= 0) dslot[s_ey] = -1;
+                dslot[D] = my; dtime[D] = step;
+                smask[my >> 5] &= ~(1u << (my & 31));
+                s_fresh_x = (nextx >= 0 && nextx != my) ? nextx : -1;
+                s_fresh_y = my;
+                s_fresh_tag = step + 1;
+                s_fresh_local = (nextx >= c0 && nextx < c1) ? 1 : 0;
+            }
+            D++;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains before the next exchange signals
+        __syncthreads();
+    }
+    __syncthreads();
+    if (wg != 0) return;
+    // chain entries this epoch wrote into a private copy: workgroup 0's copy is the one the next epoch reads
+    for (int i = tid; i < nwords; i += NN_THREADS) w.alive[i] = alive[i];
+    for (int i = tid; i < n; i += NN_THREADS) { w.size[i] = lsize[i]; w.gtime[i] = -1; }
+    __syncthreads();
+    if (tid < D) {
+        w.dslot[tid] = dslot[tid]; w.dtime[tid] = dtime[tid];
+    }
+    __syncthreads();
+    if (tid < D && dslot[tid] >= 0) w.gtime[dslot[tid]] = dtime[tid];
+    if (tid == 0) {
+        w.state[0] = step; w.state[1] = len; w.state[2] = top; w.state[3] = second; w.state[4] = first_ptr;
+        w.state[5] = s_stop; w.state[6] = D;
+    }
+}
+
 // Full-chip flush of the deferred column writes: for every dirty cluster d (time td) and every live
 // row i that did not merge after td, W[i][d] = W[d][i].  Reads are coalesced along row d.
 __global__ __launch_bounds__(256) void k_nn_flush(double* __restrict__ W, int64_t ld, int n, NNWorkspace w)
@@ -438,6 +791,13 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
 {
     int epochs = 0;
     NNWorkspace w = carve(workspace, n);
+    // Column-sliced chain on several workgroups (k_nn_epoch_mw): its fixed cost per scan (one exchange) is paid back
+    // by the shorter streams from about 16k live columns on (12.5 us per merge at 16k either way; at 32k 18.8 -> 12.8).
+    // HICMI_NNCHAIN_WGS = 1, 2, 4 or 8 forces a width for every epoch (tests, A/B).
+    const char* wgs_text = getenv("HICMI_NNCHAIN_WGS");
+    const int wgs_env = wgs_text ? atoi(wgs_text) : 0;
+    const int wgs = wgs_text ? (wgs_env >= 8 ? 8 : (wgs_env >= 4 ? 4 : (wgs_env >= 2 ? 2 : 1))) : 8;
+    const int mw_from = wgs_text ? 64 * wgs : 20000;          // live columns from which an epoch runs sliced
     if (dcap < 1) dcap = 1;
     if (dcap > NN_DMAX) dcap = NN_DMAX;
     hipLaunchKernelGGL(k_nn_init, dim3(64), dim3(256), 0, s, w, n);
@@ -449,11 +809,20 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
         size_t lds_max = align16((size_t)nw4 * 8 + (size_t)n * 2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mw<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mw<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mw<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     }
     while (done < total_steps) {
         const int nwords = (n_cur + 31) / 32, nw4 = (nwords + 3) & ~3;
         const size_t lds = align16((size_t)nw4 * 8 + (size_t)n_cur * 2);
         if (profile) hipLaunchKernelGGL(k_nn_epoch<true>, dim3(1), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+        else if (wgs > 1 && n_cur >= mw_from) {
+            hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 384, s);      // hand-off slot + mailboxes
+            if (wgs == 2) hipLaunchKernelGGL(k_nn_epoch_mw<2>, dim3(2), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+            else if (wgs == 4) hipLaunchKernelGGL(k_nn_epoch_mw<4>, dim3(4), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+            else hipLaunchKernelGGL(k_nn_epoch_mw<8>, dim3(8), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+        }
         else hipLaunchKernelGGL(k_nn_epoch<false>, dim3(1), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
         epochs++;
         const int did = total_steps - done < dcap ? total_steps - done : dcap;

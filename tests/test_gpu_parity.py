@@ -112,6 +112,40 @@ def test_upgma_beyond_one_streaming_pass_bit_exact(hic, orc):
     assert np.array_equal(leaves, leaves_o)
 
 
+@pytest.mark.parametrize("wgs", [2, 4, 8])
+@pytest.mark.parametrize("n,seed,dcap", [(130, 1, 7), (600, 2, 64), (1025, 6, 1024), (2500, 7, 1024), (4099, 8, 300)])
+def test_upgma_column_sliced_chain_bit_exact(hic, orc, monkeypatch, n, seed, dcap, wgs):
+    """k_nn_epoch_mw: the chain as 2, 4 or 8 workgroups that each stream a slice of the columns and exchange their
+    (min, index) once per scan (default from 20,000 live columns; forced here for every epoch that is wide
+    enough).  Run three times: the exchange is timing-dependent, the linkage must not be."""
+    monkeypatch.setenv("HICMI_NNCHAIN_WGS", str(wgs))
+    monkeypatch.setenv("HICMI_NNCHAIN_DCAP", str(dcap))
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, n)) + 0.01
+    c = c + c.T
+    for _ in range(3):
+        leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, c)
+        assert np.array_equal(zraw, zraw_o)
+        assert np.array_equal(leaves, leaves_o)
+    ties = rng.integers(1, 4, size=(n, n)).astype(np.float64)
+    ties = np.triu(ties, 1) + np.triu(ties, 1).T + np.eye(n)
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, ties)
+    assert np.array_equal(zraw, zraw_o)
+    assert np.array_equal(leaves, leaves_o)
+
+
+def test_upgma_column_sliced_chain_default_width_at_scale(hic, orc):
+    """21,000 bins: above the width switch, so the first epochs run on 8 workgroups and the later ones - once
+    compaction has shrunk the matrix below it - on one, sharing the saved chain state."""
+    n = 21000
+    rng = np.random.default_rng(43)
+    c = rng.random((n, n), dtype=np.float32).astype(np.float64) + 0.01
+    c = c + c.T
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, c)
+    assert np.array_equal(zraw, zraw_o)
+    assert np.array_equal(leaves, leaves_o)
+
+
 def test_exact_division_by_cluster_size_selftest(hic):
     """k_nnchain's 3-instruction division by (nx+ny) against the '/' operator: 2^29 random operands."""
     with hic.Context(0) as ctx:
