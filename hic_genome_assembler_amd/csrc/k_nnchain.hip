@@ -440,9 +440,12 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__
     int D = 0;
     uint32_t xbit = 0u;
     unsigned int xseq = 0u;                                  // exchanges so far (uniform)
+    unsigned long long tp[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+    const bool prof = w.state[7] != 0 && wg == 0 && tid == 0;
     int lowmark = len;                                       // lane 0: chain entries below this are still the earlier epochs'
 
     for (; step < total_steps && D < dcap; step++) {
+        if (prof) t0 = wall_clock64();
         if (tid == 0 && len == 0) {
             while (first_ptr < n && !((alive[first_ptr >> 5] >> (first_ptr & 31)) & 1u)) first_ptr++;
             chain[0] = first_ptr; ring[0] = first_ptr; ring_lo = 0; top = first_ptr; second = -1; len = 1;
@@ -460,6 +463,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__
             const int x = s_x, prev = s_prev;
             if (tid < D && dslot[tid] == x) s_tx = dtime[tid];
             __syncthreads();
+            if (prof) { t1 = wall_clock64(); tp[0] += t1 - t0; t0 = t1; }
             const int tx = s_tx;
             const double* __restrict__ rowx = W + (int64_t)x * ld;
             const bool use_fresh = (s_fresh_x == x);
@@ -514,6 +518,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__
             best = argmin_wave(best);
             if (lane == 0) { s_v[wave] = best.v; s_i[wave] = best.i; }
             __syncthreads();
+            if (prof) { t1 = wall_clock64(); tp[1] += t1 - t0; t0 = t1; }
             xseq++;
             if (wave == 0) {
                 ArgMin m = {lane < 16 ? s_v[lane] : __builtin_inf(), lane < 16 ? s_i[lane] : 0x7fffffff};
@@ -554,6 +559,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__
                 }
             }
             __syncthreads();
+            if (prof) { t1 = wall_clock64(); tp[2] += t1 - t0; t0 = t1; }
             if (s_done) break;
         }
         if (s_stop) break;
@@ -594,6 +600,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__
             if (dslot[tid] == my) { s_ty = dtime[tid]; s_ey = tid; }
         }
         __syncthreads();
+        if (prof) { t1 = wall_clock64(); tp[3] += t1 - t0; t0 = t1; }
         {
             const int tmx = s_tx, tmy = s_ty, nextx = s_nextx;
             const double fx = (double)s_nx, fy = (double)s_ny, fs = (double)(s_nx + s_ny);
@@ -664,6 +671,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains before the next exchange signals
         __syncthreads();
+        if (prof) { t1 = wall_clock64(); tp[4] += t1 - t0; }
     }
     __syncthreads();
     if (wg != 0) return;
@@ -679,6 +687,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__
     if (tid == 0) {
         w.state[0] = step; w.state[1] = len; w.state[2] = top; w.state[3] = second; w.state[4] = first_ptr;
         w.state[5] = s_stop; w.state[6] = D;
+        if (prof) for (int q = 0; q < 5; q++) w.prof[q] += tp[q];
     }
 }
 
@@ -801,6 +810,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     if (dcap < 1) dcap = 1;
     if (dcap > NN_DMAX) dcap = NN_DMAX;
     hipLaunchKernelGGL(k_nn_init, dim3(64), dim3(256), 0, s, w, n);
+    if (profile) { static const int one = 1; hipMemcpyAsync(w.state + 7, &one, sizeof(int), hipMemcpyHostToDevice, s); }
     const int total_steps = n - 1;
     int n_cur = n, done = 0, interval_start = 0;
     double *cur = W, *other = W2;
@@ -816,7 +826,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     while (done < total_steps) {
         const int nwords = (n_cur + 31) / 32, nw4 = (nwords + 3) & ~3;
         const size_t lds = align16((size_t)nw4 * 8 + (size_t)n_cur * 2);
-        if (profile) hipLaunchKernelGGL(k_nn_epoch<true>, dim3(1), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+        if (profile && !(wgs_text && wgs > 1)) hipLaunchKernelGGL(k_nn_epoch<true>, dim3(1), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
         else if (wgs > 1 && n_cur >= mw_from) {
             hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 384, s);      // hand-off slot + mailboxes
             if (wgs == 2) hipLaunchKernelGGL(k_nn_epoch_mw<2>, dim3(2), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
