@@ -146,6 +146,31 @@ def test_upgma_column_sliced_chain_default_width_at_scale(hic, orc):
     assert np.array_equal(leaves, leaves_o)
 
 
+def test_upgma_widths_agree_at_32k(hic, monkeypatch):
+    """BASELINE's 32,000-bin size, where SciPy is too slow to ask: the default (8 column-sliced workgroups while more
+    than 20,000 columns are live) must give the very merges of the lone workgroup, which the tests above pin to
+    SciPy up to 21,000 bins."""
+    n = 32000
+    rng = np.random.default_rng(44)
+    c = rng.random((n, n), dtype=np.float32)
+    c += c.T
+    c += np.float32(0.01)
+    got = []
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(c)                       # float32 contacts are widened on the device (configs[4])
+        del c
+        for width in (None, "1"):
+            if width is None:
+                monkeypatch.delenv("HICMI_NNCHAIN_WGS", raising=False)
+            else:
+                monkeypatch.setenv("HICMI_NNCHAIN_WGS", width)
+            leaves, _z = ctx.upgma()
+            got.append((np.array(leaves), ctx.raw_merges().copy()))
+    assert np.array_equal(got[0][1], got[1][1])
+    assert np.array_equal(got[0][0], got[1][0])
+    assert sorted(got[0][0].tolist()) == list(range(n))
+
+
 def test_exact_division_by_cluster_size_selftest(hic):
     """k_nnchain's 3-instruction division by (nx+ny) against the '/' operator: 2^29 random operands."""
     with hic.Context(0) as ctx:
