@@ -441,7 +441,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__
     uint32_t xbit = 0u;
     unsigned int xseq = 0u;                                  // exchanges so far (uniform)
     unsigned long long tp[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
-    const bool prof = w.state[7] != 0 && wg == 0 && tid == 0;
+    const bool prof = w.state[8] != 0 && wg == 0 && tid == 0;
     int lowmark = len;                                       // lane 0: chain entries below this are still the earlier epochs'
 
     for (; step < total_steps && D < dcap; step++) {
@@ -810,7 +810,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     if (dcap < 1) dcap = 1;
     if (dcap > NN_DMAX) dcap = NN_DMAX;
     hipLaunchKernelGGL(k_nn_init, dim3(64), dim3(256), 0, s, w, n);
-    if (profile) { static const int one = 1; hipMemcpyAsync(w.state + 7, &one, sizeof(int), hipMemcpyHostToDevice, s); }
+    if (profile) { static const int one = 1; hipMemcpyAsync(w.state + 8, &one, sizeof(int), hipMemcpyHostToDevice, s); }
     const int total_steps = n - 1;
     int n_cur = n, done = 0, interval_start = 0;
     double *cur = W, *other = W2;
