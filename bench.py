@@ -6,13 +6,19 @@ wall-clock and bins/s).
     python bench.py --gpus 1 --steps 3 --warmup 1            # 16,000-bin map (BASELINE configs[2])
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (contract in the task prompt) with two extra objects:
-  roofline     - the kernel family that took the most device time in the timed region, its
-                 algorithmic bytes per launch / average launch duration (HIP events recorded on the
-                 library's own stream, hicmi_timing_*), against the 8 TB/s HBM peak;
-  cpu_baseline - the CPU oracle (a port of the reference's NumPy/SciPy path, oracle/) timed on this
-                 box's host cores on a smaller map of the same generator and settings.
-N > 1: every rank processes its own map (independent genomes, no data-path collective): weak scaling.
+Rank 0 prints ONE JSON line (contract in the task prompt) with these extra objects:
+  roofline       - the kernel family that took the most device time in the timed region: its ALGORITHMIC bytes per
+                   launch (for the nn-chain the kernels count the columns their row scans visit) / its
+                   average launch duration (HIP events on the library's own stream, hicmi_timing_*), against the
+                   8 TB/s HBM peak; `traffic` = HBM bytes per launch from committed rocprofv3 --pmc passes;
+  roofline_all   - the same figure for every Part 1 kernel family (one extra, untimed step with events around every
+                   launch), so the HBM-bound kernels are visible next to the latency-bound chain;
+  north_star_32k - the same step on a 32,000-bin map (north_star's single-GPU target size), a few steps;
+  cpu_baseline   - the CPU oracle (a port of the reference's NumPy/SciPy path, oracle/) timed on this box's host
+                   cores on BASELINE configs[0] (2,000 bins), with and without the reference's unused
+                   frozen-distribution construction (scaffoldToChromosomes.py:364).
+N > 1: ONE map over all ranks (strong scaling): Part 1's row-independent stages and Part 2's chromosomes are
+sharded (hic_genome_assembler_amd/dist.py); --weak runs one independent map per rank instead.
 """
 import argparse
 import contextlib
@@ -29,6 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+PMC_KERNELS = {"nnchain": ("hicmi::k_nn_epoch", ), "sort_rows": ("hicmi::k_sort_rows", ), "row_sums": ("hicmi::k_row_sums", ),
+               "build_w": ("hicmi::k_build_w", ), "rank_invert": ("hicmi::k_rank_invert", ), "cut_count": ("hicmi::k_cut", )}
 
 
 def make_bins(lay, Bin):
@@ -43,10 +51,29 @@ def write_sizes(lay, path):
             fh.write("%s\t%d\n" % (name, size))
 
 
+def workload_label(n, part1_only, f32=False):
+    what = "-part1 only" if part1_only else "full -part1 -part2"
+    if n == 16000:
+        cfg = "BASELINE.json configs[%d]" % (1 if part1_only else 2)
+    elif n == 32000:
+        cfg = "the map of BASELINE.json configs[3] on ONE GPU (north_star's single-GPU target size)"
+    elif n == 64000:
+        cfg = "the map of BASELINE.json configs[4] on ONE GPU, %s contacts" % ("fp32" if f32 else "fp64")
+    elif n == 2000:
+        cfg = "the map of BASELINE.json configs[0]"
+    else:
+        cfg = "not a BASELINE.json size"
+    return "%d-bin synthetic ICE-balanced map, %s (%s), contacts resident in HBM" % (n, what, cfg)
+
+
 def cpu_baseline(sample_bins, n_scaffolds, scan_scaffolds, work):
-    """Time the CPU oracle on a bounded sample (resident matrix in, files out - same boundary as the GPU step)."""
+    """the CPU oracle on configs[0] (resident matrix in, files out - the same boundary as the GPU
+    step), one core; Part 1 with and without the reference's frozen-distribution construction (S2C:364), whose cost is
+    measured on a sample of the argument tuples the run really evaluated and scaled to their number."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
     import hic_oracle as orc
+    from scipy.stats import hypergeom
     from hic_genome_assembler_amd import synth
     lay = synth.make_layout(sample_bins, seed=1)
     c = synth.dense_contacts(lay, seed=1, sinkhorn_iters=12)
@@ -55,18 +82,177 @@ def cpu_baseline(sample_bins, n_scaffolds, scan_scaffolds, work):
     write_sizes(lay, sizes)
     f = lambda k: os.path.join(work, "cpu_" + k)  # noqa: E731
     orc.lib()
-    t0 = time.time()
-    orc.run_part1(None, None, None, sizes, f("dendro"), f("bingroups"), f("assess"), f("chromgroups"),
-                  min_size=5, modularity=0.0, psig=.05, preloaded=(c, bins))
-    t1 = time.time()
+    calls = {"n": 0, "args": []}
+    plain = orc.hyper_geom
+
+    def counting(x, M, n, N):
+        xs = np.atleast_1d(np.asarray(x))
+        calls["n"] += xs.size
+        if len(calls["args"]) < 4000:
+            ns, Ns = np.broadcast_to(np.asarray(n), xs.shape), np.broadcast_to(np.asarray(N), xs.shape)
+            for k in range(0, xs.size, max(1, xs.size // 8)):
+                calls["args"].append((int(M), int(ns.flat[k]), int(Ns.flat[k])))
+        return plain(x, M, n, N)
+    orc.hyper_geom = counting
+    try:
+        t0 = time.time()
+        orc.run_part1(None, None, None, sizes, f("dendro"), f("bingroups"), f("assess"), f("chromgroups"),
+                      min_size=5, modularity=0.0, psig=.05, preloaded=(c, bins))
+        t1 = time.time()
+    finally:
+        orc.hyper_geom = plain
     orc.run_part2(None, None, None, f("chromgroups"), f("orders"), f("plotorder"), n_scaffolds=n_scaffolds,
                   scan_scaffolds=scan_scaffolds, preloaded=(c, make_bins(lay, orc.Bin)))
     t2 = time.time()
+    sample = calls["args"][:3000]
+    ta = time.time()
+    with np.errstate(all="ignore"):
+        for (M, n, N) in sample:
+            hypergeom(M, n, N)                                   # S2C:364: built per call, never used
+    frozen_each = (time.time() - ta) / max(len(sample), 1)
+    frozen_total = frozen_each * calls["n"]
     return dict(value=sample_bins / (t2 - t0), unit="bins/s", cores=1, kind="port",
-                sample="%d-bin synthetic map, same generator and settings (minSize 5, modularity 0, nScaffolds %d, "
-                       "scanScaffolds %d); part1 %.1f s + part2 %.1f s on 1 of %d host cores; NumPy/SciPy oracle "
-                       "without the reference's unused frozen-distribution construction (S2C:364)"
-                       % (sample_bins, n_scaffolds, scan_scaffolds, t1 - t0, t2 - t1, os.cpu_count() or 0))
+                value_with_frozen_object=sample_bins / (t2 - t0 + frozen_total),
+                part1_s=round(t1 - t0, 2), part2_s=round(t2 - t1, 2), frozen_object_s=round(frozen_total, 2),
+                hyper_geom_evaluations=calls["n"],
+                sample="BASELINE.json configs[0]: %d-bin synthetic map, same generator and settings (minSize 5, modularity 0, "
+                       "nScaffolds %d, scanScaffolds %d), resident matrix in / files out, 1 of %d host cores; NumPy/SciPy "
+                       "oracle.  `value` is without the reference's unused frozen-distribution construction (S2C:364); "
+                       "`value_with_frozen_object` adds it: %.2f ms per construction (measured on %d of the run's own "
+                       "argument tuples) x %d evaluations (the reference's futile window retries, S2C:499-508, excluded)"
+                       % (sample_bins, n_scaffolds, scan_scaffolds, os.cpu_count() or 0, frozen_each * 1e3, len(sample),
+                          calls["n"]))
+
+
+def pmc_traffic(n, fam):
+    """HBM bytes per launch of a kernel family from the latest committed rocprofv3 --pmc collection for this map size
+    (profiles/r*_pmc_part1_<n/1000>k.json; 2 x FETCH_SIZE + WRITE_SIZE: MI355X_MICROARCH.md, FETCH_SIZE counts half
+    of a wide coalesced read stream on gfx950).  PMC collection cannot run inside the timed process."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_part1_%dk.json" % (n // 1000))))
+    if not files or fam not in PMC_KERNELS:
+        return None, None
+    with open(files[-1]) as fh:
+        pmc = json.load(fh)
+    fetch = write = 0.0
+    dispatches = 0
+    for name, d in pmc.get("FETCH_SIZE", {}).items():
+        if name.startswith(PMC_KERNELS[fam]):
+            fetch += d["sum_KB"]
+            dispatches += d["dispatches"]
+    for name, d in pmc.get("WRITE_SIZE", {}).items():
+        if name.startswith(PMC_KERNELS[fam]):
+            write += d["sum_KB"]
+    if not dispatches:
+        return None, None
+    return ((2.0 * fetch + write) * 1024.0 / dispatches,
+            "profiles/%s (rocprofv3 --pmc passes, 2*FETCH_SIZE + WRITE_SIZE per dispatch)" % os.path.basename(files[-1]))
+
+
+def family_table(timing, steps, n):
+    out = {}
+    for k, v in timing.items():
+        if v["launches"] == 0 or v["ms"] <= 0 or v["bytes"] <= 0 or k.startswith("p2_") or k == "plot":
+            continue
+        avg_ms = v["ms"] / v["launches"]
+        gbs = v["bytes"] / v["launches"] / (avg_ms * 1e-3) / 1e9
+        traffic, _src = pmc_traffic(n, k)
+        out[k] = {"ms_per_step": round(v["ms"] / steps, 3), "launches_per_step": v["launches"] / steps,
+                  "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": v["bytes"] / v["launches"],
+                  "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic}
+    return out
+
+
+class Job:
+    """One resident map and the contexts that process it."""
+
+    def __init__(self, args, n, dev, local, seed, shard, f32=False):
+        import torch
+        from hic_genome_assembler_amd import _lib, synth
+        from hic_genome_assembler_amd.hostio import Bin
+        self.args, self.n, self.shard = args, n, shard
+        self.lay = synth.make_layout(n, seed=seed)
+        self.contacts = synth.dense_contacts_torch(self.lay, dev, seed=seed, sinkhorn_iters=12)
+        if f32:                                            # configs[4]: contacts stored as fp32 (exactly representable values)
+            self.contacts = self.contacts.to(torch.float32).to(torch.float64)
+        torch.cuda.synchronize()
+        self.work = tempfile.mkdtemp(prefix="hicbench_")
+        self.sizes = os.path.join(self.work, "synth.sizes")
+        write_sizes(self.lay, self.sizes)
+        self.ctx = _lib.Context(local)
+        self.bins = make_bins(self.lay, Bin)               # the .bed metadata, parsed once like the matrix
+        self.last = {}
+
+    def f(self, k):
+        return os.path.join(self.work, k)
+
+    def step(self):
+        from hic_genome_assembler_amd import orderGenome as p2, scaffoldToChromosomes as p1
+        a, f = self.args, self.f
+        self.ctx.set_contacts_device(self.contacts.data_ptr(), self.n, keepalive=self.contacts)
+        dm = p1.DeviceMatrix(self.ctx)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ta = time.perf_counter()
+            cuts = p1.runResident(dm, list(self.bins), self.sizes, f("dendrogramOrder.txt"), f("binGroups.txt"),
+                                  f("assessment.txt"), f("chromosomeGroups.txt"), 5, 0.0, .05, shard=self.shard)
+            self.last["part1_s"] = time.perf_counter() - ta
+            if not a.part1_only:
+                p2.runResident(p2.GenomeMatrix(self.ctx), dm.kept_bins, f("chromosomeGroups.txt"),
+                               f("chromosomeOrders.txt"), f("plotOrder.txt"), a.n_scaffolds, a.scan_scaffolds,
+                               self.lay.resolution, shard=self.shard)
+        self.last["part2_s"] = time.perf_counter() - ta - self.last["part1_s"]
+        self.last["cuts"] = cuts
+
+    def close(self):
+        self.ctx.close()
+        shutil.rmtree(self.work, ignore_errors=True)
+
+
+def timed_run(job, steps, warmup, timing_mode, barrier, reduce_dev):
+    import torch
+    from hic_genome_assembler_amd import dist
+    for _ in range(warmup):
+        job.step()
+    job.ctx.timing_enable(timing_mode)
+    job.ctx.timing_reset()
+    barrier()
+    torch.cuda.synchronize()
+    job.ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.step()
+    job.ctx.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0, device=reduce_dev)
+    timing = job.ctx.timing()
+    stats = job.ctx.nnchain_stats()
+    job.ctx.timing_enable(False)
+    return elapsed, timing, stats
+
+
+def roofline_of(timing, stats, steps, n, workers):
+    # Part 2 families are summed over the concurrent worker streams (and the queued insertion is timed as
+    # one region per chromosome), so their wall-clock share is about 1/workers of the sum
+    fam = max(timing, key=lambda k: timing[k]["ms"] / (workers if k.startswith("p2_") else 1))
+    d = timing[fam]
+    avg_ms = d["ms"] / max(d["launches"], 1)
+    bytes_per_launch = d["bytes"] / max(d["launches"], 1)
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(n, fam)
+    out = {"bound": "hbm", "kernel": fam, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+           "avg_launch_ms": avg_ms, "launches_per_step": d["launches"] / max(steps, 1),
+           "algorithmic_bytes_per_launch": bytes_per_launch}
+    if fam == "nnchain" and stats["merges"] > 0:
+        nominal = 3.5 * n * n * 8.0 * steps                 # SURVEY 8d's nominal figure for SciPy's loop (~3 scans per merge)
+        out.update({"definition": "8 B x (columns visited by the row scans the kernels really ran + 3 x live columns per "
+                                  "merge), counted by the kernels (SURVEY 8d); latency-bound: the meaningful rate is merges/s",
+                    "merges_per_s": stats["merges"] / (d["ms"] * 1e-3) if d["ms"] > 0 else None,
+                    "row_scans_per_merge": stats["scans"] / stats["merges"],
+                    "chain_steps_from_neighbour_cache_per_merge": stats["cache_hits"] / stats["merges"],
+                    "achieved_nominal_3.5N2": nominal / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else None,
+                    "frac_nominal_3.5N2": nominal / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if d["ms"] > 0 else None})
+    return out
 
 
 def main():
@@ -78,11 +264,14 @@ def main():
     ap.add_argument("--n-scaffolds", type=int, default=6)
     ap.add_argument("--scan-scaffolds", type=int, default=5)
     ap.add_argument("--part1-only", action="store_true", help="BASELINE configs[1]: clustering + cuts only")
-    ap.add_argument("--cpu-sample-bins", type=int, default=1500)
+    ap.add_argument("--f32", action="store_true", help="contacts rounded to fp32 values (BASELINE configs[4] stores fp32)")
+    ap.add_argument("--cpu-sample-bins", type=int, default=2000, help="BASELINE configs[0]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--one-map", action="store_true",
-                    help="N > 1: ONE map on all ranks (strong scaling) - Part 1 replicated, Part 2's chromosomes dealt "
-                         "to the ranks, orders all-gathered; the default is one independent map per rank (weak)")
+    ap.add_argument("--no-32k", action="store_true", help="skip the north_star_32k object")
+    ap.add_argument("--no-table", action="store_true", help="skip the extra untimed step behind roofline_all")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: one independent map per rank (weak scaling) instead of ONE map over all ranks")
+    ap.add_argument("--one-map", action="store_true", help="(default for N > 1; kept for earlier command lines)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearse the multi-rank flow with several ranks on one GPU")
     ap.add_argument("--kernel-times", choices=["part1", "all"], default="part1",
@@ -93,131 +282,89 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
+    n_devices = max(1, torch.cuda.device_count())
     if args.backend == "gloo":                          # rehearsal: more ranks than GPUs share the cards
-        local %= max(1, torch.cuda.device_count())
+        local %= n_devices
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from hic_genome_assembler_amd import _lib, dist, synth
+    from hic_genome_assembler_amd import dist
     dist.init(args.backend, device=dev)                 # RCCL; no-op for one process
-    one_map = args.one_map and world > 1
+    one_map = world > 1 and not args.weak
     shard = (rank, world) if one_map else None
-    map_seed = 1 if one_map else 1 + rank
+    map_seed = 1 if (one_map or world == 1) else 1 + rank
     reduce_dev = dev if args.backend == "nccl" else None
-    from hic_genome_assembler_amd import orderGenome as p2, scaffoldToChromosomes as p1
-    from hic_genome_assembler_amd.hostio import Bin
+    from hic_genome_assembler_amd import orderGenome as p2
 
     n = args.bins
-    lay = synth.make_layout(n, seed=map_seed)
-    contacts = synth.dense_contacts_torch(lay, dev, seed=map_seed, sinkhorn_iters=12)
-    torch.cuda.synchronize()
-    work = tempfile.mkdtemp(prefix="hicbench_r%d_" % rank)
-    sizes = os.path.join(work, "synth.sizes")
-    write_sizes(lay, sizes)
-    f = lambda k: os.path.join(work, k)  # noqa: E731
-    ctx = _lib.Context(local)
-    last = {}
-    bin_objects = make_bins(lay, Bin)                   # the .bed metadata, parsed once like the matrix
-
-    def step():
-        ctx.set_contacts_device(contacts.data_ptr(), n, keepalive=contacts)
-        dm = p1.DeviceMatrix(ctx)
-        with contextlib.redirect_stdout(io.StringIO()):
-            ta = time.perf_counter()
-            cuts = p1.runResident(dm, list(bin_objects), sizes, f("dendrogramOrder.txt"), f("binGroups.txt"),
-                                  f("assessment.txt"), f("chromosomeGroups.txt"), 5, 0.0, .05)
-            last["part1_s"] = time.perf_counter() - ta
-            if not args.part1_only:
-                p2.runResident(p2.GenomeMatrix(ctx), dm.kept_bins, f("chromosomeGroups.txt"),
-                               f("chromosomeOrders.txt"), f("plotOrder.txt"), args.n_scaffolds, args.scan_scaffolds,
-                               lay.resolution, shard=shard)
-        last["part2_s"] = time.perf_counter() - ta - last["part1_s"]
-        last["cuts"] = cuts
-
-    barrier = dist.barrier
-
-    for _ in range(args.warmup):
-        step()
+    job = Job(args, n, dev, local, map_seed, shard, f32=args.f32)
+    timing_mode = 0 if os.environ.get("HICMI_BENCH_NO_TIMING") else (1 if args.kernel_times == "all" else 2)
     # HIP events around the families that decide the roofline line (nn-chain, row sort, ...).  --kernel-times all
     # also brackets the hundreds of small launches of the scans and of Part 2, which costs about 10 ms per map.
-    ctx.timing_enable(0 if os.environ.get("HICMI_BENCH_NO_TIMING") else (1 if args.kernel_times == "all" else 2))
-    ctx.timing_reset()
-    barrier()
-    torch.cuda.synchronize()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = dist.max_over_ranks(time.perf_counter() - t0, device=reduce_dev)
-    timing = ctx.timing()
-    ctx.timing_enable(False)
+    elapsed, timing, stats = timed_run(job, args.steps, args.warmup, timing_mode, dist.barrier, reduce_dev)
 
+    out = None
     if rank == 0:
-        ms_per_step = elapsed / max(args.steps, 1) * 1e3
+        steps = max(args.steps, 1)
+        ms_per_step = elapsed / steps * 1e3
         value = (1 if one_map else world) * n / (ms_per_step / 1e3)
-        # Part 2 families are summed over the concurrent worker streams (and the queued insertion is timed as
-        # one region per chromosome), so their wall-clock share is about 1/workers of the sum
         workers = max(1, min(p2.WORKERS, 8))
-        fam = max(timing, key=lambda k: timing[k]["ms"] / (workers if k.startswith("p2_") else 1))
-        d = timing[fam]
-        avg_ms = d["ms"] / max(d["launches"], 1)
-        bytes_per_launch = d["bytes"] / max(d["launches"], 1)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this very command
-        # (FETCH_SIZE, WRITE_SIZE; MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide coalesced read stream),
-        # stored under profiles/: PMC collection cannot run inside the timed process.
-        traffic, traffic_src = None, None
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_part1_16k.json")))
-        pmc_file = pmc_files[-1] if pmc_files else ""             # the latest committed collection
-        pmc_kernel = {"nnchain": "hicmi::k_nn_epoch<false>", "sort_rows": "hicmi::k_sort_rows_rb"}.get(fam)
-        if n == 16000 and pmc_kernel and os.path.exists(pmc_file):
-            with open(pmc_file) as fh:
-                pmc = json.load(fh)
-            f_kb = pmc["FETCH_SIZE"].get(pmc_kernel)
-            w_kb = pmc["WRITE_SIZE"].get(pmc_kernel)
-            if f_kb and w_kb:
-                traffic = (2.0 * f_kb["sum_KB"] + w_kb["sum_KB"]) * 1024.0 / max(f_kb["dispatches"], 1)
-                traffic_src = ("profiles/%s (rocprofv3 --pmc passes, 2*FETCH_SIZE + WRITE_SIZE per dispatch)"
-                               % os.path.basename(pmc_file))
+        lay, last = job.lay, job.last
         out = {
             "metric": "Part1+Part2 wall-clock (s) and bins/s on N x N contact map" if not args.part1_only
                       else "Part1 wall-clock (s) and bins/s on N x N contact map",
-            "value": value, "unit": "bins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "bins/s", "n_gpus": world if args.backend == "nccl" else min(world, n_devices),
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if one_map else "weak",
             "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("%d-bin synthetic ICE-balanced map, %s on 1xMI355X per rank "
-                                    "(BASELINE.json configs[%d]), contacts resident in HBM"
-                                    % (n, "-part1 only" if args.part1_only else "full -part1 -part2",
-                                       1 if args.part1_only else 2)),
+            "config": {"workload": workload_label(n, args.part1_only, args.f32),
                        "bins": n, "chromosomes_planted": int(lay.chrom_of_bin.max()) + 1,
                        "scaffolds": len(lay.scaffold_names), "cuts_found": len(last.get("cuts", [])),
                        "minSize": 5, "modularity": 0, "psig": 0.05, "nScaffolds": args.n_scaffolds,
                        "scanScaffolds": args.scan_scaffolds, "wall_clock_s": ms_per_step / 1e3,
                        "last_step_part1_s": round(last.get("part1_s", 0.0), 4),
                        "last_step_part2_s": round(last.get("part2_s", 0.0), 4),
-                       "part2_workers": p2.WORKERS,
-                       "parallelism": ("one map over %d GPUs: Part 1 replicated, Part 2 chromosomes dealt to the ranks, "
-                                       "object all-gather of the orders" % world) if one_map
-                                      else "1 map per GPU, no collective" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": fam, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_launch_ms": avg_ms, "launches_per_step": d["launches"] / max(args.steps, 1),
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
-            "kernels_ms_per_step": {k: round(v["ms"] / max(args.steps, 1), 3) for k, v in timing.items()
+                       "part2_workers": p2.WORKERS, "ranks": world,
+                       "parallelism": ("ONE map over %d ranks: Part 1's row-independent stages (row sums, row sort / rank "
+                                       "matrix, cut and filter counts) row-blocked with an all-gather of the per-row counts, "
+                                       "UPGMA replicated, Part 2's chromosomes dealt to the ranks" % world) if one_map
+                                      else "1 independent map per rank, no collective" if world > 1 else "single GPU"},
+            "roofline": roofline_of(timing, stats, steps, n, workers),
+            "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in timing.items()
                                     if v["ms"] > 0 or args.kernel_times == "all"},
         }
+    if world == 1 and not args.no_table:
+        # one more step, untimed, with events around EVERY launch: the per-kernel roofline table
+        _e, t_all, _s = timed_run(job, 1, 0, 1, dist.barrier, reduce_dev)
+        out["roofline_all"] = family_table(t_all, 1, n)
+    job.close()
+    del job
+    torch.cuda.empty_cache()
+    if world == 1 and not args.no_32k and n != 32000 and not args.part1_only:
+        # north_star's single-GPU target size, same step, a few repetitions (its own synthetic map)
+        job32 = Job(args, 32000, dev, local, 1, None)
+        k32 = 3
+        e32, t32, s32 = timed_run(job32, k32, 1, timing_mode, dist.barrier, reduce_dev)
+        ms32 = e32 / k32 * 1e3
+        out["north_star_32k"] = {"workload": workload_label(32000, False), "value": 32000 / (ms32 / 1e3), "unit": "bins/s",
+                                 "ms_per_step": ms32, "steps": k32, "warmup": 1, "cuts_found": len(job32.last.get("cuts", [])),
+                                 "last_step_part1_s": round(job32.last.get("part1_s", 0.0), 4),
+                                 "last_step_part2_s": round(job32.last.get("part2_s", 0.0), 4),
+                                 "roofline": roofline_of(t32, s32, k32, 32000, max(1, min(p2.WORKERS, 8))),
+                                 "kernels_ms_per_step": {k: round(v["ms"] / k32, 3) for k, v in t32.items() if v["ms"] > 0}}
+        job32.close()
+        del job32
+        torch.cuda.empty_cache()
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
+            work = tempfile.mkdtemp(prefix="hicbench_cpu_")
             with contextlib.redirect_stdout(io.StringIO()):
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_bins, args.n_scaffolds, args.scan_scaffolds, work)
+            shutil.rmtree(work, ignore_errors=True)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    ctx.close()
-    shutil.rmtree(work, ignore_errors=True)
     if world > 1:
         dist.barrier()
         torch.distributed.destroy_process_group()

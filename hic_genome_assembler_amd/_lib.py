@@ -34,6 +34,8 @@ SIGNATURES = {
     "hicmi_contacts_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "hicmi_load_hicpro_matrix": (ctypes.c_int, [ctypes.c_char_p, _vp, c_i64, _vp, ctypes.c_int, ctypes.POINTER(c_i64)]),
     "hicmi_row_sums": (ctypes.c_int, [_vp, _vp, _vp]),
+    "hicmi_set_row_shard": (ctypes.c_int, [_vp, c_i64, c_i64]),
+    "hicmi_set_row_sums": (ctypes.c_int, [_vp, _vp, _vp]),
     "hicmi_compact": (ctypes.c_int, [_vp, _vp, c_i64]),
     "hicmi_upgma": (ctypes.c_int, [_vp, _vp, _vp]),
     "hicmi_rank_matrix": (ctypes.c_int, [_vp, _vp]),
@@ -46,6 +48,7 @@ SIGNATURES = {
     "hicmi_label_linkage": (ctypes.c_int, [_vp, c_i64, _vp]),
     "hicmi_leaf_order": (ctypes.c_int, [_vp, c_i64, _vp]),
     "hicmi_get_raw_merges": (ctypes.c_int, [_vp, _vp]),
+    "hicmi_nnchain_stats": (ctypes.c_int, [_vp, _vp]),
     "hicmi_p2_select": (ctypes.c_int, [_vp, _vp, c_i64]),
     "hicmi_p2_total": (ctypes.c_int, [_vp, ctypes.POINTER(c_dbl)]),
     "hicmi_p2_score": (ctypes.c_int, [_vp, _vp, c_i64, c_i64, c_dbl, _vp]),
@@ -164,6 +167,7 @@ class Context:
         self._keepalive = None
         self._workers = []
         self._n_window_cand = 0
+        self.shard = (0, 1)
 
     def close(self):
         for w in getattr(self, "_workers", []):
@@ -228,6 +232,19 @@ class Context:
         _check(self._lib.hicmi_row_sums(self._h, _ptr(np_sum), _ptr(seq)))
         return np_sum, seq
 
+    def set_row_shard(self, first: int, stride: int):
+        """One map over several GPUs: this context handles rows first, first + stride, ... of the row-independent
+        stages (hicmi_set_row_shard)."""
+        _check(self._lib.hicmi_set_row_shard(self._h, int(first), int(stride)))
+        self.shard = (int(first), int(stride))
+
+    def set_row_sums(self, np_sum, seq_sum):
+        a = np.ascontiguousarray(np_sum, dtype=np.float64)
+        b = np.ascontiguousarray(seq_sum, dtype=np.float64)
+        if len(a) != self.n or len(b) != self.n:
+            raise ValueError("row sums must have n entries")
+        _check(self._lib.hicmi_set_row_sums(self._h, _ptr(a), _ptr(b)))
+
     def compact(self, keep):
         keep = np.ascontiguousarray(keep, dtype=np.int32)
         _check(self._lib.hicmi_compact(self._h, _ptr(keep), len(keep)))
@@ -249,6 +266,12 @@ class Context:
         z = np.empty((max(self.n - 1, 0), 4), np.float64)
         _check(self._lib.hicmi_get_raw_merges(self._h, _ptr(z)))
         return z
+
+    def nnchain_stats(self):
+        """Counters of the nn-chain kernels since the last timing_reset (hicmi_nnchain_stats)."""
+        out = np.zeros(6, np.float64)
+        _check(self._lib.hicmi_nnchain_stats(self._h, _ptr(out)))
+        return dict(merges=out[0], scans=out[1], scan_columns=out[2], cache_hits=out[3], retries=int(out[4]))
 
     def rank_matrix(self, order):
         order = np.ascontiguousarray(order, dtype=np.int32)

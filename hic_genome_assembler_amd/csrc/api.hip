@@ -59,6 +59,8 @@ struct hicmi_ctx {
     bool own_c = false;
     double *d_np = nullptr, *d_seq = nullptr;
     bool have_sums = false;
+    // row shard (one map over several GPUs): this context sorts / counts only rows first, first + stride, ...
+    int64_t shard_first = 0, shard_stride = 1;
     // upgma
     double *dW = nullptr, *dW2 = nullptr; int64_t ldw = 0; int64_t w_rows = 0;
     int *d_size = nullptr, *d_chain = nullptr, *d_status = nullptr;
@@ -118,6 +120,8 @@ struct hicmi_ctx {
     std::vector<TimedRegion> regions;
     std::vector<hipEvent_t> pool;
     double ms[F_COUNT] = {0}; int64_t launches[F_COUNT] = {0}; double bytes[F_COUNT] = {0};
+    // nn-chain counters since the last hicmi_timing_reset (reported by hicmi_nnchain_stats)
+    double nn_scans = 0, nn_scan_cols = 0, nn_cache_hits = 0, nn_merges = 0; int64_t nn_retries = 0;
 };
 
 namespace {
@@ -250,7 +254,7 @@ int compute_sums(hicmi_ctx* c)
     if (!c->dC) return fail(HICMI_EINVAL, "no contact matrix set");
     {
         Timed t(c, F_ROW_SUMS, 2.0 * 8.0 * (double)c->n * (double)c->n);
-        launch_row_sums(c->dC, c->ldc, (int)c->n, c->d_np, c->d_seq, c->stream);
+        launch_row_sums(c->dC, c->ldc, (int)c->n, c->d_np, c->d_seq, 0, 1, c->stream);
     }
     HIPCHK(hipGetLastError());
     c->have_sums = true;
@@ -386,11 +390,46 @@ int hicmi_contacts_device(hicmi_ctx* c, void** d_contacts_out, int64_t* n_out, i
     return HICMI_OK;
 }
 
+int hicmi_set_row_shard(hicmi_ctx* c, int64_t first, int64_t stride)
+{
+    if (!c || stride < 1 || first < 0 || first >= stride) return fail(HICMI_EINVAL, "row shard needs 0 <= first < stride");
+    c->shard_first = first; c->shard_stride = stride;
+    c->have_rank = false; c->cached_start = -1;
+    return HICMI_OK;
+}
+
+int hicmi_set_row_sums(hicmi_ctx* c, const double* np_sum, const double* seq_sum)
+{
+    if (!c || !np_sum || !seq_sum) return fail(HICMI_EINVAL, "bad arguments");
+    if (!c->dC) return fail(HICMI_EINVAL, "no contact matrix set");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = upload(c, c->d_np, np_sum, sizeof(double) * (size_t)c->n);
+    if (rc) return rc;
+    rc = upload(c, c->d_seq, seq_sum, sizeof(double) * (size_t)c->n);
+    if (rc) return rc;
+    HIPCHK(sync_stream(c));
+    c->have_sums = true;
+    return HICMI_OK;
+}
+
 int hicmi_row_sums(hicmi_ctx* c, double* np_sum, double* seq_sum)
 {
     if (!c) return fail(HICMI_EINVAL, "NULL context");
     HIPCHK(hipSetDevice(c->device));
-    int rc = compute_sums(c);
+    int rc = HICMI_OK;
+    if (c->shard_stride > 1 && !c->have_sums) {
+        // this shard's rows only (the other entries read 0); the caller gathers the shards and hands the complete
+        // vectors back with hicmi_set_row_sums
+        if (!c->dC) return fail(HICMI_EINVAL, "no contact matrix set");
+        HIPCHK(hipMemsetAsync(c->d_np, 0, sizeof(double) * (size_t)c->n, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_seq, 0, sizeof(double) * (size_t)c->n, c->stream));
+        {
+            Timed t(c, F_ROW_SUMS, 2.0 * 8.0 * (double)c->n * (double)c->n / (double)c->shard_stride);
+            launch_row_sums(c->dC, c->ldc, (int)c->n, c->d_np, c->d_seq, (int)c->shard_first, (int)c->shard_stride, c->stream);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    else rc = compute_sums(c);
     if (rc) return rc;
     if (np_sum) { rc = download(c, np_sum, c->d_np, sizeof(double) * (size_t)c->n); if (rc) return rc; }
     if (seq_sum) { rc = download(c, seq_sum, c->d_seq, sizeof(double) * (size_t)c->n); if (rc) return rc; }
@@ -525,35 +564,54 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         launch_build_w(c->dC, c->ldc, c->d_np, (int)n, c->dW, ldw, c->stream);
     }
     HIPCHK(hipGetLastError());
-    {
-        // nominal algorithmic traffic of SciPy's nn_chain: <=3(n-1) row scans + per merge two row reads,
-        // one row write and one column write of 8-byte elements
-        Timed t(c, F_NNCHAIN, 8.0 * 7.0 * (double)n * (double)(n - 1));
-        const char* cap = getenv("HICMI_NNCHAIN_DCAP");           // merges between two column flushes (tests shrink it)
-        int epochs = launch_nnchain(c->dW, c->dW2, ldw, (int)n, c->d_chain, c->d_zraw, c->d_size,
-                                    getenv("HICMI_NNCHAIN_PROFILE") != nullptr, cap ? atoi(cap) : 1024,
-                                    getenv("HICMI_NNCHAIN_NO_COMPACT") == nullptr, c->stream);
-        // the family is reported per k_nn_epoch launch (the flush / compaction launches in between are ~1 % of it)
-        if (epochs > 1) c->launches[F_NNCHAIN] += epochs - 1;
+    // The nn-chain.  Algorithmic bytes: 8 B x (sum over row scans of the live columns + 3 x sum over merges
+    // of the live columns), with the scans counted by the kernels themselves (a scan the neighbour cache answers moves
+    // nothing); the merge term is 3 * 8 * sum_{k=0}^{n-2} (n - k).
+    const bool prof_on = getenv("HICMI_NNCHAIN_PROFILE") != nullptr;
+    const char* cap = getenv("HICMI_NNCHAIN_DCAP");               // merges between two column flushes (tests shrink it)
+    struct { int state[16]; unsigned long long prof[8]; } nn;      // the head of the workspace
+    for (int attempt = 0; attempt < 2; attempt++) {
+        {
+            Timed t(c, F_NNCHAIN, 0.0);
+            int epochs = launch_nnchain(c->dW, c->dW2, ldw, (int)n, c->d_chain, c->d_zraw, c->d_size, prof_on,
+                                        cap ? atoi(cap) : 1024, getenv("HICMI_NNCHAIN_NO_COMPACT") == nullptr, attempt > 0, c->stream);
+            // the family is reported per epoch launch (the flush / compaction launches in between are ~1 % of it)
+            if (epochs > 1) c->launches[F_NNCHAIN] += epochs - 1;
+        }
+        HIPCHK(hipGetLastError());
+        int rc_dl = download(c, &nn, nnchain_state_ptr(c->d_size), sizeof(nn));
+        if (rc_dl) return rc_dl;
+        c->bytes[F_NNCHAIN] += 8.0 * ((double)nn.prof[5] + 3.0 * (0.5 * (double)(n - 1) * (double)(n + 2)));
+        c->nn_scans += (double)nn.prof[6]; c->nn_scan_cols += (double)nn.prof[5]; c->nn_cache_hits += (double)nn.prof[7];
+        c->nn_merges += (double)(n - 1);
+        if (nn.state[5] != 2 || attempt > 0) break;
+        // A peer workgroup of the column-sliced chain did not answer within its spin budget (a GPU shared with other
+        // work can delay a workgroup's start): nothing is wrong with the data.  Rebuild the distances and run the whole
+        // chain again on one workgroup, which waits for nobody.
+        fprintf(stderr, "[hicmi] nn-chain: a peer workgroup answered late at merge %d; re-running on one workgroup\n", nn.state[0]);
+        c->nn_retries++;
+        launch_build_w(c->dC, c->ldc, c->d_np, (int)n, c->dW, ldw, c->stream);
+        HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipGetLastError());
-    int status = 0;
     c->zraw.assign((size_t)(4 * (n - 1)), 0.0);
-    int nn_state[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     {
-        int rc_dl = download(c, nn_state, nnchain_state_ptr(c->d_size), sizeof(nn_state));
-        if (rc_dl) return rc_dl;
-        rc_dl = download(c, c->zraw.data(), c->d_zraw, sizeof(double) * 4 * (size_t)(n - 1));
+        int rc_dl = download(c, c->zraw.data(), c->d_zraw, sizeof(double) * 4 * (size_t)(n - 1));
         if (rc_dl) return rc_dl;
     }
-    if (getenv("HICMI_NNCHAIN_PROFILE")) {
-        unsigned long long pr[5] = {0, 0, 0, 0, 0};
-        HIPCHK(hipMemcpy(pr, nnchain_prof_ptr(c->d_size), sizeof(pr), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[hicmi] nnchain phases (ms @100MHz): bookkeeping %.2f scan %.2f pick %.2f merge %.2f update %.2f\n",
-                pr[0] / 1e5, pr[1] / 1e5, pr[2] / 1e5, pr[3] / 1e5, pr[4] / 1e5);
+    if (prof_on) {
+        const unsigned long long* pr = nn.prof;
+        fprintf(stderr, "[hicmi] nnchain phases (ms @100MHz): bookkeeping %.2f scan %.2f pick %.2f merge %.2f update %.2f; "
+                        "%llu scans (%.2f per merge), %llu cached steps\n",
+                pr[0] / 1e5, pr[1] / 1e5, pr[2] / 1e5, pr[3] / 1e5, pr[4] / 1e5, pr[6], (double)pr[6] / (double)(n - 1), pr[7]);
     }
-    status = nn_state[5] != 0 || nn_state[0] != (int)(n - 1);
-    if (status != 0) return fail(HICMI_ESTATE, "nn-chain kernel stopped on its guard (NaN distances or an internal error)");
+    if (nn.state[5] == 2)
+        return fail(HICMI_ESTATE, "nn-chain: a peer workgroup of the column-sliced kernel answered late, and so did the retry");
+    if (nn.state[5] == 3)
+        return fail(HICMI_ESTATE, "nn-chain: the replicas of the column-sliced kernel disagree about a merge (stale read between "
+                                  "workgroups); set HICMI_NNCHAIN_WGS=1 to run on one workgroup");
+    if (nn.state[5] != 0 || nn.state[0] != (int)(n - 1))
+        return fail(HICMI_ESTATE, "nn-chain kernel stopped on its guard at merge %d of %lld (NaN distances or an internal error)",
+                    nn.state[0], (long long)(n - 1));
     std::vector<double> Z((size_t)(4 * (n - 1)));
     rc = hicmi_label_linkage(c->zraw.data(), n, Z.data());
     if (rc) return rc;
@@ -568,6 +626,14 @@ int hicmi_get_raw_merges(hicmi_ctx* c, double* out)
     if (!c || !out) return fail(HICMI_EINVAL, "bad arguments");
     if (c->zraw.empty()) return fail(HICMI_EINVAL, "hicmi_upgma has not run");
     memcpy(out, c->zraw.data(), sizeof(double) * c->zraw.size());
+    return HICMI_OK;
+}
+
+int hicmi_nnchain_stats(hicmi_ctx* c, double* out6)
+{
+    if (!c || !out6) return fail(HICMI_EINVAL, "bad arguments");
+    out6[0] = c->nn_merges; out6[1] = c->nn_scans; out6[2] = c->nn_scan_cols; out6[3] = c->nn_cache_hits;
+    out6[4] = (double)c->nn_retries; out6[5] = 0.0;
     return HICMI_OK;
 }
 
@@ -605,15 +671,16 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
         int rc_up = upload(c, c->d_order, both.data(), sizeof(int32_t) * both.size());
         if (rc_up) return rc_up;
     }
+    const double share = 1.0 / (double)c->shard_stride;             // this shard's rows only
     {
-        Timed t(c, F_SORT, (8.0 + 2.0) * (double)n * (double)n);
+        Timed t(c, F_SORT, (8.0 + 2.0) * (double)n * (double)n * share);
         launch_sort_rows(c->dC, c->ldc, c->d_order, c->d_order + n, c->d_np, c->d_seq, (int)n, c->d_sort_scratch, c->dR, ldr,
-                         c->stream);
+                         (int)c->shard_first, (int)c->shard_stride, c->stream);
     }
     HIPCHK(hipGetLastError());
     {
-        Timed t(c, F_RANK_INVERT, (2.0 + 2.0) * (double)n * (double)n);
-        launch_rank_invert(c->dR, c->dRank, ldr, (int)n, c->stream);
+        Timed t(c, F_RANK_INVERT, (2.0 + 2.0) * (double)n * (double)n * share);
+        launch_rank_invert(c->dR, c->dRank, ldr, (int)n, (int)c->shard_first, (int)c->shard_stride, c->stream);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(sync_stream(c));
@@ -664,14 +731,14 @@ static int ensure_scan_buffers(hicmi_ctx* c)
 // The significance flags of the rows counted in d_x.  The flags are all the host loops need, tens of thousands of
 // times per map: the kernel writes them straight into the pinned buffer (no copy kernel, one synchronisation).
 static int finish_scan(hicmi_ctx* c, int64_t rows, int mode, int64_t L_fixed, int64_t M, double psig, int32_t* x_out,
-                       uint8_t* sig_out)
+                       uint8_t* sig_out, int64_t own_first)
 {
     const bool direct = sig_out && !x_out;
     if (direct) { int rc = ensure_pin_down(c, (size_t)rows); if (rc) return rc; }
     {
         Timed t(c, F_HYPER_FLAGS, 5.0 * (double)rows);
         launch_hyper_flags(c->d_x, (int)rows, mode, (int)L_fixed, M, psig, direct ? reinterpret_cast<uint8_t*>(c->pin_down) : c->d_sig,
-                           c->stream);
+                           (int)own_first, (int)c->shard_stride, c->stream);
     }
     HIPCHK(hipGetLastError());
     if (direct) {
@@ -695,15 +762,19 @@ int hicmi_cut_scan(hicmi_ctx* c, int64_t start, int64_t M, double psig, int32_t*
     int rc = ensure_scan_buffers(c);
     if (rc) return rc;
     const int64_t cnt = n - start;              // entries: rows start .. n-1
+    const int64_t st = c->shard_stride;
+    const int64_t t0 = ((c->shard_first - start) % st + st) % st;      // first entry whose row this shard owns
     if (c->cached_start != start) {
-        HIPCHK(hipMemsetAsync(c->d_x, 0, sizeof(int32_t), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_x, 0, sizeof(int32_t) * (size_t)(st > 1 ? cnt : 1), c->stream));
         const double m = (double)(cnt - 1);
-        Timed t(c, F_CUT_COUNT, 2.0 * (m * (m + 3.0) / 2.0));      // sum_{L=1..m} (L+1) uint16 entries
-        launch_cut_count(c->dRank, c->ldr, (int)start + 1, (int)(cnt - 1), (int)start, 0, 0, c->d_x + 1, c->stream);
+        Timed t(c, F_CUT_COUNT, 2.0 * (m * (m + 3.0) / 2.0) / (double)st);      // sum_{L=1..m} (L+1) uint16 entries
+        const int64_t t1 = t0 >= 1 ? t0 : t0 + st;                      // entry 0 (the row `start` itself) is never counted
+        if (t1 < cnt)
+            launch_cut_count(c->dRank, c->ldr, (int)(start + t1), (int)(cnt - t1), (int)start, 0, 0, c->d_x + t1, (int)st, c->stream);
         HIPCHK(hipGetLastError());
         c->cached_start = start;
     }
-    return finish_scan(c, cnt, 0, 0, M, psig, x_out, sig_out);
+    return finish_scan(c, cnt, 0, 0, M, psig, x_out, sig_out, t0);
 }
 
 int hicmi_filter_scan(hicmi_ctx* c, int64_t start, int64_t cut, int64_t n_rows, int64_t M, double psig,
@@ -718,12 +789,17 @@ int hicmi_filter_scan(hicmi_ctx* c, int64_t start, int64_t cut, int64_t n_rows, 
     int rc = ensure_scan_buffers(c);
     if (rc) return rc;
     c->cached_start = -1;                       // d_x is reused
+    const int64_t st = c->shard_stride;
+    const int64_t t0 = ((c->shard_first - start) % st + st) % st;      // first entry whose row this shard owns
+    if (st > 1) HIPCHK(hipMemsetAsync(c->d_x, 0, sizeof(int32_t) * (size_t)n_rows, c->stream));
     {
-        Timed t(c, F_CUT_COUNT, 2.0 * (double)n_rows * (double)(cut - start + 1));
-        launch_cut_count(c->dRank, c->ldr, (int)start, (int)n_rows, (int)start, 1, (int)cut, c->d_x, c->stream);
+        Timed t(c, F_CUT_COUNT, 2.0 * (double)n_rows * (double)(cut - start + 1) / (double)st);
+        if (t0 < n_rows)
+            launch_cut_count(c->dRank, c->ldr, (int)(start + t0), (int)(n_rows - t0), (int)start, 1, (int)cut, c->d_x + t0, (int)st,
+                             c->stream);
     }
     HIPCHK(hipGetLastError());
-    return finish_scan(c, n_rows, 1, cut - start, M, psig, x_out, sig_out);
+    return finish_scan(c, n_rows, 1, cut - start, M, psig, x_out, sig_out, t0);
 }
 
 double hicmi_hypergeom_sf(int64_t x, int64_t M, int64_t n, int64_t N) { return hypergeom_sf_ge(x, M, n, N); }
@@ -1656,6 +1732,7 @@ int hicmi_timing_reset(hicmi_ctx* c)
     int rc = resolve_timing(c);
     if (rc) return rc;
     for (int f = 0; f < F_COUNT; f++) { c->ms[f] = 0; c->launches[f] = 0; c->bytes[f] = 0; }
+    c->nn_scans = c->nn_scan_cols = c->nn_cache_hits = c->nn_merges = 0; c->nn_retries = 0;
     return HICMI_OK;
 }
 

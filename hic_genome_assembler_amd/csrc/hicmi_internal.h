@@ -116,7 +116,8 @@ __device__ __forceinline__ double combine_leaves(int n_leaves, const double* lea
 
 // ---- launchers (defined next to their kernels) --------------------------------------------------
 // k_part1.hip
-void launch_row_sums(const double* C, int64_t ldc, int n, double* np_sum, double* seq_sum, hipStream_t s);
+void launch_row_sums(const double* C, int64_t ldc, int n, double* np_sum, double* seq_sum, int row_first, int row_stride,
+                     hipStream_t s);
 void launch_compact(const double* src, int64_t ld_src, const int32_t* keep, int n_keep, double* dst, int64_t ld_dst,
                     hipStream_t s);
 void launch_widen_f32(const float* src, double* dst, int64_t cells, hipStream_t s);   // src = (float*)dst + cells
@@ -124,22 +125,25 @@ void launch_build_w(const double* C, int64_t ldc, const double* np_sum, int n, d
 // k_nnchain.hip
 size_t nnchain_workspace_bytes(int n);
 int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double* zraw, void* workspace, bool profile,
-                   int dcap, bool compact, hipStream_t s);   // returns the number of k_nn_epoch launches
+                   int dcap, bool compact, bool force_single, hipStream_t s);   // returns the number of epoch launches
 void launch_selftest_division(unsigned long long seed, int blocks, int iters, unsigned long long* d_mismatches, hipStream_t s);
-const int* nnchain_state_ptr(void* workspace);                    // [0] merges done ... [5] guard tripped
-const unsigned long long* nnchain_prof_ptr(void* workspace);      // 5 phase totals (100 MHz ticks)
+const int* nnchain_state_ptr(void* workspace);                    // 16 ints: [0] merges done ... [5] stop code (0 = none,
+                                                                  // 1 = guard / NaN, 2 = a peer workgroup answered late, 3 = replicas disagree)
+const unsigned long long* nnchain_prof_ptr(void* workspace);      // 8 counters, contiguous after the state: [0..4] phase totals
+                                                                  // (100 MHz ticks), [5] columns visited by scans, [6] scans, [7] cache hits
 void launch_cut_count(const uint16_t* rank, int64_t ldr, int row0, int nrows, int lo, int mode, int cparam,
-                      int32_t* x_out, hipStream_t s);
+                      int32_t* x_out, int row_step, hipStream_t s);
 void launch_hyper_flags(const int32_t* x, int nrows, int mode, int L_fixed, int64_t M, double psig, uint8_t* sig,
-                        hipStream_t s);
+                        int own_first, int own_step, hipStream_t s);
 
 // k_sort.hip
 int  sort_padded_size(int n);                 // power of two >= n
 int  sort_workgroups(int n);                  // persistent workgroups the sort kernel wants
 size_t sort_scratch_bytes(int n);             // device scratch (keys + indices) for all workgroups
 void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const int32_t* inv, const double* np_sum,
-                      const double* seq_sum, int n, void* scratch, uint16_t* R, int64_t ldr, hipStream_t s);
-void launch_rank_invert(const uint16_t* R, uint16_t* rank, int64_t ldr, int n, hipStream_t s);
+                      const double* seq_sum, int n, void* scratch, uint16_t* R, int64_t ldr, int row_first, int row_stride,
+                      hipStream_t s);
+void launch_rank_invert(const uint16_t* R, uint16_t* rank, int64_t ldr, int n, int row_first, int row_stride, hipStream_t s);
 void launch_similarity_row(const double* C, int64_t ldc, const int32_t* order, const double* np_sum,
                            const double* seq_sum, int n, int row, double* out, hipStream_t s);
 

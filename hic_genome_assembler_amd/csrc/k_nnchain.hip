@@ -89,11 +89,61 @@ __device__ __forceinline__ ArgMin argmin_wave(ArgMin a)
     return m;
 }
 
+// ---- (value, index) minimum that also knows whether the minimum is attained more than once -----------------------
+// The neighbour cache (k_nn_epoch_nc) may answer "who is the nearest neighbour of x" without the distance only when
+// no second column ties with it (SciPy prefers the previous chain element on an exact tie).
+struct ArgMinT { double v; int i; int t; };
+
+__device__ __forceinline__ ArgMinT argmint_join(ArgMinT a, double ov, int oi, int ot)
+{
+    if (ov < a.v || (ov == a.v && oi < a.i)) { a.t = ot | (ov == a.v ? 1 : 0); a.v = ov; a.i = oi; }
+    else if (ov == a.v && oi != a.i) a.t = 1;
+    return a;
+}
+
+template <int CTRL>
+__device__ __forceinline__ ArgMinT argmint_dpp_step(ArgMinT a)
+{
+    const int lo = __double2loint(a.v), hi = __double2hiint(a.v);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    const int oi = __builtin_amdgcn_update_dpp(a.i, a.i, CTRL, 0xf, 0xf, false);
+    const int ot = __builtin_amdgcn_update_dpp(a.t, a.t, CTRL, 0xf, 0xf, false);
+    return argmint_join(a, __hiloint2double(ohi, olo), oi, ot);
+}
+
+__device__ __forceinline__ ArgMinT argmint_row16(ArgMinT a)
+{
+    a = argmint_dpp_step<0xB1>(a);
+    a = argmint_dpp_step<0x4E>(a);
+    a = argmint_dpp_step<0x141>(a);
+    a = argmint_dpp_step<0x140>(a);
+    return a;
+}
+
+__device__ __forceinline__ ArgMinT argmint_wave(ArgMinT a)
+{
+    a = argmint_row16(a);
+    ArgMinT m;
+    m.v = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a.v), 0), __builtin_amdgcn_readlane(__double2loint(a.v), 0));
+    m.i = __builtin_amdgcn_readlane(a.i, 0);
+    m.t = __builtin_amdgcn_readlane(a.t, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const double ov = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a.v), r), __builtin_amdgcn_readlane(__double2loint(a.v), r));
+        m = argmint_join(m, ov, __builtin_amdgcn_readlane(a.i, r), __builtin_amdgcn_readlane(a.t, r));
+    }
+    return m;
+}
+
 // workspace layout (all 16-byte aligned)
 struct NNWorkspace {
-    int* state;                 // [0] step [1] len [2] top [3] second [4] first_ptr [5] stop [6] n_dirty
-    unsigned long long* prof;   // 6 phase totals
-    void* mail;                 // k_nn_epoch_mw: 2 x NN_MAXWG 16-byte mailbox slots
+    int* state;                 // [0] step [1] len [2] top [3] second [4] first_ptr [5] stop code [6] n_dirty [7] n after compaction
+                                // [8] profile on [9] first step of the epoch that ran last [10] test: exchange that is declared late
+                                // [11] test: step whose record replica 1 falsifies
+    unsigned long long* prof;   // [0..4] phase totals (100 MHz ticks), [5] columns visited by row scans, [6] row scans,
+                                // [7] chain steps answered by the neighbour cache
+    void* mail;                 // k_nn_epoch_mw: 2 x NN_MAXWG 16-byte mailbox slots; k_nn_epoch_mwc: two slots per workgroup
     uint32_t* alive;            // nwords
     uint16_t* size;             // n
     int* gtime;                 // n: dirty time stamp of a slot in the finished epoch, -1 = clean
@@ -102,14 +152,20 @@ struct NNWorkspace {
     int* orig;                  // n: original bin of each current slot (changes at every compaction)
     int* newidx;                // n: scratch of the compaction (old slot -> new slot, -1 = dead)
     int* oldidx;                // n: scratch of the compaction (new slot -> old slot)
+    double* nnval;              // n: neighbour cache - distance to the nearest live cluster of each slot
+    uint32_t* nnc;              // n: neighbour cache - its slot (low 16 bits, 0xffff = unknown) | tie flag << 16
+    double* rec;                // NN_MAXWG x NN_DMAX x 4: the merges of the last epoch as every replica of k_nn_epoch_mw saw them
 };
+static constexpr int NN_STOP_GUARD = 1, NN_STOP_LATE = 2, NN_STOP_DIVERGED = 3;
+static constexpr uint32_t NN_NOIDX = 0xffffu;
 
 static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 size_t nnchain_workspace_bytes(int n)
 {
     size_t nwords = (size_t)(n + 31) / 32;
-    return 512 + align16(nwords * 4) + align16((size_t)n * 2) + 4 * align16((size_t)n * 4) + 2 * align16(NN_DMAX * 4);
+    return 1024 + align16(nwords * 4) + align16((size_t)n * 2) + 4 * align16((size_t)n * 4) + 2 * align16(NN_DMAX * 4) +
+           align16((size_t)n * 8) + align16((size_t)n * 4) + (size_t)NN_MAXWG * NN_DMAX * 4 * 8;
 }
 
 static NNWorkspace carve(void* ws, int n)
@@ -119,8 +175,8 @@ static NNWorkspace carve(void* ws, int n)
     NNWorkspace w;
     w.state = reinterpret_cast<int*>(p);
     w.prof = reinterpret_cast<unsigned long long*>(p + 64);
-    w.mail = p + 256;
-    p += 512;
+    w.mail = p + 256;                                        // 2 parities x NN_MAXWG workgroups x 2 slots x 16 bytes
+    p += 1024;
     w.alive = reinterpret_cast<uint32_t*>(p); p += align16(nwords * 4);
     w.size = reinterpret_cast<uint16_t*>(p); p += align16((size_t)n * 2);
     w.gtime = reinterpret_cast<int*>(p); p += align16((size_t)n * 4);
@@ -128,7 +184,10 @@ static NNWorkspace carve(void* ws, int n)
     w.dtime = reinterpret_cast<int*>(p); p += align16(NN_DMAX * 4);
     w.orig = reinterpret_cast<int*>(p); p += align16((size_t)n * 4);
     w.newidx = reinterpret_cast<int*>(p); p += align16((size_t)n * 4);
-    w.oldidx = reinterpret_cast<int*>(p);
+    w.oldidx = reinterpret_cast<int*>(p); p += align16((size_t)n * 4);
+    w.nnval = reinterpret_cast<double*>(p); p += align16((size_t)n * 8);
+    w.nnc = reinterpret_cast<uint32_t*>(p); p += align16((size_t)n * 4);
+    w.rec = reinterpret_cast<double*>(p);
     return w;
 }
 
@@ -175,7 +234,8 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
     // lane-0 private chain state
     int len = w.state[1], top = w.state[2], second = w.state[3], first_ptr = w.state[4], ring_lo = len;
     unsigned long long t_book = 0, t_scan = 0, t_pick = 0, t_merge = 0, t_upd = 0, t0 = 0, t1 = 0;
-    if (tid == 0) { s_stop = 0; s_done = 0; }
+    unsigned long long c_cols = 0, c_scans = 0;
+    if (tid == 0) { s_stop = 0; s_done = 0; w.state[9] = step; }
     __syncthreads();
     int D = 0;                                              // dirty entries (uniform across lanes)
     uint32_t xbit = 0u;                                     // lane 0: the scan row's own bit in smask
@@ -194,6 +254,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
                 s_x = top; s_prev = (len > 1) ? second : -1; s_tx = -1;
                 xbit = smask[top >> 5] & (1u << (top & 31));         // the row's own column is skipped by masking it
                 smask[top >> 5] &= ~xbit;
+                c_scans++; c_cols += (unsigned long long)(total_steps + 1 - step);
             }
             __syncthreads();
             const int x = s_x, prev = s_prev;
@@ -328,6 +389,320 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch(double* __restrict__ W,
     if (tid == 0) {
         w.state[0] = step; w.state[1] = len; w.state[2] = top; w.state[3] = second; w.state[4] = first_ptr;
         w.state[5] = s_stop; w.state[6] = D;
+        w.prof[5] += c_cols; w.prof[6] += c_scans;
+        if (PROFILE) { w.prof[0] += t_book; w.prof[1] += t_scan; w.prof[2] += t_pick; w.prof[3] += t_merge; w.prof[4] += t_upd; }
+    }
+}
+
+// ---- the chain with a neighbour cache (k_nn_epoch_nc) ----------------------------------------------------------
+// SciPy's nn_chain re-scans a whole row at EVERY chain step: ~2.9 scans per merge on the Hi-C maps.  Most of those
+// scans re-derive what is already known: the nearest neighbour of a row changes only when (a) that neighbour
+// merges, or (b) a freshly merged cluster lands closer - and (b) is seen by the Lance-Williams update, which
+// computes d(i, new) for every live i anyway.  So every slot keeps (nnval, nnidx, tie): distance and LOWEST slot of
+// its nearest live cluster, and whether a second column attains the same distance.
+//   update of merge (x, y) -> y : for every live j  v = d(j, y')
+//        nnidx[j] in {x, y}                       -> unknown (the row is scanned when the chain next visits it)
+//        v <  nnval[j]                            -> unknown              (fp rounding can do this: reducibility is not exact)
+//        v == nnval[j]                            -> (v, min(nnidx[j], y'), tie)
+//      and the new row's own minimum is reduced in the same pass (4 of 5 merged clusters are visited again).
+//   chain step at x with previous element p: SciPy takes  argmin_{i != x} d(x, i)  with ties to the LOWEST index, but
+//      prefers p when d(x, p) equals the minimum.  With the cache: nnidx[x] == p -> reciprocal pair; no tie flag ->
+//      nnidx[x] (it is strictly closer than p); tie flag -> scan the row (the value decides).  The merge height
+//      d(x, p) is read by one lane during the update, off the critical path.
+// Result: ~1.26 scans per merge instead of ~2.9, every one of them a row whose neighbour really is unknown; the
+// chain steps in between are a few LDS reads by lane 0.  Tie-heavy inputs fall back to scans and stay exact.
+// Everything else (deferred column writes, epochs, compaction, DPP reductions) is k_nn_epoch's.
+static constexpr int NN_NC_MAX = 24576;                  // largest live width whose cache fits the LDS next to the sizes
+
+__global__ __launch_bounds__(256) void k_nn_rowmin(const double* __restrict__ W, int64_t ld, int n, NNWorkspace w)
+{
+    __shared__ double s_v[4];
+    __shared__ int s_i[4], s_t[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (!((w.alive[r >> 5] >> (r & 31)) & 1u)) { if (tid == 0) w.nnc[r] = NN_NOIDX; return; }
+    const double* __restrict__ row = W + (int64_t)r * ld;
+    ArgMinT best = {__builtin_inf(), 0x7fffffff, 0};
+    for (int j = tid * 2; j < n; j += 512) {                 // ascending j per lane; ld is a multiple of 16 and padding is +inf
+        const double2 v = *reinterpret_cast<const double2*>(row + j);
+        const uint32_t bits = w.alive[j >> 5] >> (j & 31);
+        if ((bits & 1u) && j != r && v.x <= best.v) { if (v.x < best.v) { best.v = v.x; best.i = j; best.t = 0; } else best.t = 1; }
+        if ((bits & 2u) && j + 1 != r && j + 1 < n && v.y <= best.v) { if (v.y < best.v) { best.v = v.y; best.i = j + 1; best.t = 0; } else best.t = 1; }
+    }
+    best = argmint_wave(best);
+    if ((tid & 63) == 0) { s_v[tid >> 6] = best.v; s_i[tid >> 6] = best.i; s_t[tid >> 6] = best.t; }
+    __syncthreads();
+    if (tid == 0) {
+        ArgMinT m = {s_v[0], s_i[0], s_t[0]};
+        for (int q = 1; q < 4; q++) m = argmint_join(m, s_v[q], s_i[q], s_t[q]);
+        w.nnval[r] = m.v;
+        w.nnc[r] = (m.i >= 0 && m.i < n) ? ((uint32_t)m.i | ((uint32_t)(m.t ? 1 : 0) << 16)) : NN_NOIDX;
+    }
+}
+
+template <bool PROFILE>
+__global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_nc(double* __restrict__ W, int64_t ld, int n,
+                                                            int* __restrict__ chain, double* __restrict__ zraw,
+                                                            NNWorkspace w, int dcap, int total_steps)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_nn[];
+    const int nwords = (n + 31) >> 5, nw4 = (nwords + 3) & ~3, n2 = (n + 7) & ~7;
+    uint32_t* alive = reinterpret_cast<uint32_t*>(smem_nn);
+    uint32_t* smask = alive + nw4;                          // alive AND not dirty: what the streaming passes visit
+    uint32_t* tieb = smask + nw4;                           // the cached minimum of the slot is attained more than once
+    uint16_t* lsize = reinterpret_cast<uint16_t*>(tieb + nw4);
+    uint16_t* nnidx = lsize + n2;                           // cached nearest slot, NN_NOIDX = unknown
+    __shared__ int dslot[NN_DMAX], dtime[NN_DMAX];
+    __shared__ double s_v[16];
+    __shared__ int s_i[16], s_t[16];
+    __shared__ int ring[256];
+    __shared__ double s_dprev;
+    __shared__ int s_x, s_prev, s_act, s_stop, s_mx, s_my, s_nx, s_ny, s_tx, s_ty, s_ey;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The cached distances are streamed by every update and must not be stored to inside that loop: a store through
+    // the same pointer makes the compiler order every later load of the unrolled loop behind it - one memory round trip
+    // per iteration instead of one per pass (measured: update 39 -> 107 ms at 16k).  So a row whose new distance is
+    // strictly SMALLER than its cached minimum (fp rounding; rare) simply loses its cache entry; only lane 0 stores
+    // distances (scan results, the merged row's minimum), between the passes.
+    const double* nnval_ld = w.nnval;
+    int step = w.state[0];
+    if (step >= total_steps || w.state[5]) {               // finished (or stopped) in an earlier epoch
+        if (tid == 0) w.state[6] = 0;
+        return;
+    }
+    for (int i = tid; i < nwords; i += NN_THREADS) { alive[i] = w.alive[i]; smask[i] = w.alive[i]; tieb[i] = 0u; }
+    __syncthreads();
+    for (int i = tid; i < n; i += NN_THREADS) {
+        lsize[i] = w.size[i]; w.gtime[i] = -1;
+        const uint32_t c = w.nnc[i];
+        nnidx[i] = (uint16_t)(c & 0xffffu);
+        if (c >> 16) atomicOr(&tieb[i >> 5], 1u << (i & 31));
+    }
+    // lane-0 private chain state
+    int len = w.state[1], top = w.state[2], second = w.state[3], first_ptr = w.state[4], ring_lo = len;
+    unsigned long long t_book = 0, t_scan = 0, t_pick = 0, t_merge = 0, t_upd = 0, t0 = 0, t1 = 0;
+    unsigned long long c_cols = 0, c_scans = 0, c_hits = 0;
+    if (tid == 0) { s_stop = 0; w.state[9] = step; }
+    __syncthreads();
+    int D = 0;                                              // dirty entries (uniform across lanes)
+    uint32_t xbit = 0u;                                     // lane 0: the scan row's own bit in smask
+    int guard = 0, stop_code = 0;                           // lane 0
+    bool stopped = false;                                   // uniform
+
+    for (; step < total_steps && D < dcap; step++) {
+        if (PROFILE && tid == 0) t0 = wall_clock64();
+        while (true) {
+            // ---- walk the chain on cached neighbours (lane 0) until a row has to be scanned or a pair is reciprocal
+            if (tid == 0) {
+                if (len == 0) {
+                    while (first_ptr < n && !((alive[first_ptr >> 5] >> (first_ptr & 31)) & 1u)) first_ptr++;
+                    chain[0] = first_ptr; ring[0] = first_ptr; ring_lo = 0; top = first_ptr; second = -1; len = 1;
+                }
+                int act = 0;                                 // 1: scan row `top`, 2: merge (top, second), 3: stop
+                while (act == 0) {
+                    const int x = top, prev = (len > 1) ? second : -1;
+                    const uint32_t idx = nnidx[x];
+                    if (idx == NN_NOIDX) act = 1;
+                    else if ((int)idx == prev) act = 2;
+                    else if (prev >= 0 && ((tieb[x >> 5] >> (x & 31)) & 1u)) act = 1;      // an exact tie: the value decides
+                    else if (++guard > 4 * n + 8) { stop_code = NN_STOP_GUARD; act = 3; }
+                    else {
+                        chain[len] = (int)idx; ring[len & 255] = (int)idx;
+                        if (len - 255 > ring_lo) ring_lo = len - 255;
+                        second = top; top = (int)idx; len++;
+                        c_hits++;
+                    }
+                }
+                s_act = act; s_x = top; s_prev = (len > 1) ? second : -1; s_tx = -1;
+                if (act == 1) {
+                    xbit = smask[top >> 5] & (1u << (top & 31));     // the row's own column is skipped by masking it
+                    smask[top >> 5] &= ~xbit;
+                    c_scans++; c_cols += (unsigned long long)(total_steps + 1 - step);
+                }
+            }
+            __syncthreads();
+            if (s_act != 1) break;
+            // ---- scan row x: lexicographic (value, index) minimum over the live columns, and whether it is unique
+            const int x = s_x, prev = s_prev;
+            if (tid < D && dslot[tid] == x) s_tx = dtime[tid];       // is the row itself dirty, and since when
+            __syncthreads();
+            if (PROFILE && tid == 0) { t1 = wall_clock64(); t_book += t1 - t0; t0 = t1; }
+            const int tx = s_tx;
+            const double* __restrict__ rowx = W + (int64_t)x * ld;
+            if (tid == 64 && prev >= 0 && ((smask[prev >> 5] >> (prev & 31)) & 1u)) s_dprev = rowx[prev];
+            ArgMinT cand = {__builtin_inf(), 0x7fffffff, 0};
+            if (tid < D) {
+                const int d = dslot[tid];
+                if (d >= 0 && d != x && ((alive[d >> 5] >> (d & 31)) & 1u)) {
+                    const double v = dtime[tid] > tx ? W[(int64_t)d * ld + x] : rowx[d];
+                    cand.v = v; cand.i = d;
+                    if (d == prev) s_dprev = v;
+                }
+            }
+            ArgMinT best = {__builtin_inf(), 0x7fffffff, 0};
+#pragma unroll 8
+            for (int j = tid * 2; j < n; j += 2 * NN_THREADS) {     // ascending j per lane: the first of equal values stays
+                double2 v = *reinterpret_cast<const double2*>(rowx + j);
+                uint32_t bits = smask[j >> 5] >> (j & 31);          // j even: both bits in one word; bits past n are 0
+                if ((bits & 1u) && v.x <= best.v) { if (v.x < best.v) { best.v = v.x; best.i = j; best.t = 0; } else best.t = 1; }
+                if ((bits & 2u) && v.y <= best.v) { if (v.y < best.v) { best.v = v.y; best.i = j + 1; best.t = 0; } else best.t = 1; }
+            }
+            if (cand.i != 0x7fffffff) best = argmint_join(best, cand.v, cand.i, 0);
+            best = argmint_wave(best);
+            if (lane == 0) { s_v[wave] = best.v; s_i[wave] = best.i; s_t[wave] = best.t; }
+            __syncthreads();
+            if (PROFILE && tid == 0) { t1 = wall_clock64(); t_scan += t1 - t0; t0 = t1; }
+            if (wave == 0) {
+                ArgMinT m = {lane < 16 ? s_v[lane] : __builtin_inf(), lane < 16 ? s_i[lane] : 0x7fffffff, lane < 16 ? s_t[lane] : 0};
+                m = argmint_row16(m);                               // the 16 wave results sit in row 0
+                if (lane == 0) {
+                    smask[x >> 5] |= xbit;                          // un-mask the row's own column
+                    if (m.i < 0 || m.i >= n) { s_stop = NN_STOP_GUARD; stop_code = NN_STOP_GUARD; }   // NaN distances: nothing compares
+                    else {
+                        nnidx[x] = (uint16_t)m.i;
+                        if (m.t) tieb[x >> 5] |= (1u << (x & 31)); else tieb[x >> 5] &= ~(1u << (x & 31));
+                        w.nnval[x] = m.v;
+                        // SciPy: the previous chain element wins unless something is STRICTLY closer
+                        int y = m.i;
+                        if (prev >= 0 && !(m.v < s_dprev)) y = prev;
+                        if (y != prev) {
+                            if (++guard > 4 * n + 8) { s_stop = NN_STOP_GUARD; stop_code = NN_STOP_GUARD; }
+                            chain[len] = y; ring[len & 255] = y;
+                            if (len - 255 > ring_lo) ring_lo = len - 255;
+                            second = top; top = y; len++;
+                        } else {
+                            // reciprocal by the tie rule although the cache names another column: let the walk see it
+                            nnidx[x] = (uint16_t)prev;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (PROFILE && tid == 0) { t1 = wall_clock64(); t_pick += t1 - t0; t0 = t1; }
+            if (s_stop) { stopped = true; break; }
+        }
+        if (stopped || s_act == 3) break;
+        // ---- merge (top, second)
+        if (tid == 0) {
+            int xx = top, yy = second;
+            len -= 2;
+            if (xx > yy) { int t = xx; xx = yy; yy = t; }
+            int nx = lsize[xx], ny = lsize[yy];
+            zraw[4 * (int64_t)step + 0] = (double)xx;
+            zraw[4 * (int64_t)step + 1] = (double)yy;
+            zraw[4 * (int64_t)step + 3] = (double)(nx + ny);
+            lsize[xx] = 0;
+            lsize[yy] = (uint16_t)(nx + ny);
+            alive[xx >> 5] &= ~(1u << (xx & 31));
+            smask[xx >> 5] &= ~(1u << (xx & 31));
+            s_mx = xx; s_my = yy; s_nx = nx; s_ny = ny; s_tx = -1; s_ty = -1; s_ey = -1;
+            top = len >= 1 ? (len - 1 >= ring_lo ? ring[(len - 1) & 255] : chain[len - 1]) : -1;
+            second = len >= 2 ? (len - 2 >= ring_lo ? ring[(len - 2) & 255] : chain[len - 2]) : -1;
+        }
+        __syncthreads();
+        const int mx = s_mx, my = s_my;
+        if (tid < D) {
+            if (dslot[tid] == mx) s_tx = dtime[tid];
+            if (dslot[tid] == my) { s_ty = dtime[tid]; s_ey = tid; }
+        }
+        __syncthreads();
+        if (PROFILE && tid == 0) { t1 = wall_clock64(); t_merge += t1 - t0; t0 = t1; }
+        {
+            const int tmx = s_tx, tmy = s_ty;
+            const double fx = (double)s_nx, fy = (double)s_ny, fs = (double)(s_nx + s_ny);
+            const double rcp = 1.0 / fs;
+            const double* __restrict__ rx = W + (int64_t)mx * ld;
+            double* __restrict__ ry = W + (int64_t)my * ld;
+            // the merge height d(x, y): the row of whichever cluster merged last is the authoritative one (column mx of
+            // row my is not rewritten below: mx is dead)
+            if (tid == NN_THREADS - 1) zraw[4 * (int64_t)step + 2] = tmx > tmy ? rx[my] : ry[mx];
+            ArgMinT rbest = {__builtin_inf(), 0x7fffffff, 0};   // minimum of the new row: the merged cluster's own cache entry
+            // dirty partners first (their loads overlap the streaming pass); results are stored after
+            // the streaming pass has rewritten row y
+            double dv = 0.0; int dd = -1;
+            if (tid < D) {
+                const int d = dslot[tid];
+                if (d >= 0 && d != my && ((alive[d >> 5] >> (d & 31)) & 1u)) {
+                    const double dxi = dtime[tid] > tmx ? W[(int64_t)d * ld + mx] : rx[d];
+                    const double dyi = dtime[tid] > tmy ? W[(int64_t)d * ld + my] : ry[d];
+                    const double nvd = nnval_ld[d];
+                    dv = div_by_small_int(fx * dxi + fy * dyi, fs, rcp);
+                    dd = d;
+                    const uint32_t id = nnidx[d];
+                    if (id == (uint32_t)mx || id == (uint32_t)my) nnidx[d] = (uint16_t)NN_NOIDX;
+                    else if (id != NN_NOIDX && dv <= nvd) {
+                        if (dv < nvd) nnidx[d] = (uint16_t)NN_NOIDX;
+                        else { if ((uint32_t)my < id) nnidx[d] = (uint16_t)my; atomicOr(&tieb[d >> 5], 1u << (d & 31)); }
+                    }
+                }
+            }
+#pragma unroll 4
+            for (int j = tid * 2; j < n; j += 2 * NN_THREADS) {
+                double2 a = *reinterpret_cast<const double2*>(rx + j);
+                double2 b = *reinterpret_cast<const double2*>(ry + j);
+                const double2 nv = *reinterpret_cast<const double2*>(nnval_ld + j);
+                const uint32_t ip = *reinterpret_cast<const uint32_t*>(nnidx + j);
+                uint32_t bits = smask[j >> 5] >> (j & 31);
+                if ((bits & 1u) && j != my) {
+                    b.x = div_by_small_int(fx * a.x + fy * b.x, fs, rcp);
+                    if (b.x <= rbest.v) { if (b.x < rbest.v) { rbest.v = b.x; rbest.i = j; rbest.t = 0; } else rbest.t = 1; }
+                    const uint32_t id = ip & 0xffffu;
+                    if (id == (uint32_t)mx || id == (uint32_t)my) nnidx[j] = (uint16_t)NN_NOIDX;
+                    else if (id != NN_NOIDX && b.x <= nv.x) {
+                        if (b.x < nv.x) nnidx[j] = (uint16_t)NN_NOIDX;
+                        else { if ((uint32_t)my < id) nnidx[j] = (uint16_t)my; atomicOr(&tieb[j >> 5], 1u << (j & 31)); }
+                    }
+                }
+                if ((bits & 2u) && j + 1 != my) {
+                    b.y = div_by_small_int(fx * a.y + fy * b.y, fs, rcp);
+                    if (b.y <= rbest.v) { if (b.y < rbest.v) { rbest.v = b.y; rbest.i = j + 1; rbest.t = 0; } else rbest.t = 1; }
+                    const uint32_t id = ip >> 16;
+                    if (id == (uint32_t)mx || id == (uint32_t)my) nnidx[j + 1] = (uint16_t)NN_NOIDX;
+                    else if (id != NN_NOIDX && b.y <= nv.y) {
+                        if (b.y < nv.y) nnidx[j + 1] = (uint16_t)NN_NOIDX;
+                        else { if ((uint32_t)my < id) nnidx[j + 1] = (uint16_t)my; atomicOr(&tieb[(j + 1) >> 5], 1u << ((j + 1) & 31)); }
+                    }
+                }
+                *reinterpret_cast<double2*>(ry + j) = b;
+            }
+            if (dd >= 0) rbest = argmint_join(rbest, dv, dd, 0);
+            rbest = argmint_wave(rbest);
+            if (lane == 0) { s_v[wave] = rbest.v; s_i[wave] = rbest.i; s_t[wave] = rbest.t; }
+            __syncthreads();
+            if (dd >= 0) ry[dd] = dv;
+            if (wave == 0) {
+                ArgMinT m = {lane < 16 ? s_v[lane] : __builtin_inf(), lane < 16 ? s_i[lane] : 0x7fffffff, lane < 16 ? s_t[lane] : 0};
+                m = argmint_row16(m);
+                if (lane == 0) {                             // cluster y is dirty from now on; its neighbour is known
+                    if (s_ey >= 0) dslot[s_ey] = -1;         // its older entry is superseded
+                    dslot[D] = my; dtime[D] = step;
+                    smask[my >> 5] &= ~(1u << (my & 31));
+                    if (m.i >= 0 && m.i < n) {
+                        nnidx[my] = (uint16_t)m.i; w.nnval[my] = m.v;
+                        if (m.t) tieb[my >> 5] |= (1u << (my & 31)); else tieb[my >> 5] &= ~(1u << (my & 31));
+                    } else nnidx[my] = (uint16_t)NN_NOIDX;
+                }
+            }
+            D++;
+        }
+        __syncthreads();
+        if (PROFILE && tid == 0) { t1 = wall_clock64(); t_upd += t1 - t0; }
+    }
+    // ---- save state for the flush kernel and the next epoch
+    __syncthreads();
+    for (int i = tid; i < nwords; i += NN_THREADS) w.alive[i] = alive[i];
+    for (int i = tid; i < n; i += NN_THREADS) {
+        w.size[i] = lsize[i];
+        w.nnc[i] = (uint32_t)nnidx[i] | (((tieb[i >> 5] >> (i & 31)) & 1u) << 16);
+    }
+    if (tid < D) {
+        w.dslot[tid] = dslot[tid]; w.dtime[tid] = dtime[tid];
+        if (dslot[tid] >= 0) w.gtime[dslot[tid]] = dtime[tid];
+    }
+    if (tid == 0) {
+        w.state[0] = step; w.state[1] = len; w.state[2] = top; w.state[3] = second; w.state[4] = first_ptr;
+        w.state[5] = stop_code; w.state[6] = D;
+        w.prof[5] += c_cols; w.prof[6] += c_scans; w.prof[7] += c_hits;
         if (PROFILE) { w.prof[0] += t_book; w.prof[1] += t_scan; w.prof[2] += t_pick; w.prof[3] += t_merge; w.prof[4] += t_upd; }
     }
 }
@@ -443,6 +818,10 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__
     unsigned long long tp[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     const bool prof = w.state[8] != 0 && wg == 0 && tid == 0;
     int lowmark = len;                                       // lane 0: chain entries below this are still the earlier epochs'
+    const int step0 = step;                                  // records of this epoch: w.rec[(wg * NN_DMAX + step - step0) * 4 ..]
+    const int inject_late = w.state[10], inject_wrong = w.state[11];      // test hooks (0 = off)
+    unsigned long long c_cols = 0, c_scans = 0;
+    if (tid == 0 && wg == 0) w.state[9] = step0;
 
     for (; step < total_steps && D < dcap; step++) {
         if (prof) t0 = wall_clock64();
@@ -458,6 +837,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__
                 s_x = top; s_prev = (len > 1) ? second : -1; s_tx = -1;
                 xbit = smask[top >> 5] & (1u << (top & 31));
                 smask[top >> 5] &= ~xbit;
+                c_scans++; c_cols += (unsigned long long)(total_steps + 1 - step);
             }
             __syncthreads();
             const int x = s_x, prev = s_prev;
@@ -537,6 +917,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__
                         o.v = mw_value(r); o.i = mw_index(r);
                     }
                 }
+                if (inject_late > 0 && (int)xseq == inject_late) late = 1;      // test hook: a peer that never answers
                 late = __any(late);
                 m = argmin_row16(o);
                 if (lane == 0) {
@@ -546,7 +927,8 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__
                         if (m.v < dprev) { y = m.i; c = m.v; } else { y = prev; c = dprev; }
                     } else { y = m.i; c = m.v; }
                     int done = (prev >= 0 && y == prev);
-                    if (late || s_late || y < 0 || y >= n || ++guard > n + 2) { s_stop = 1; done = 1; }
+                    if (late || s_late) { s_stop = NN_STOP_LATE; done = 1; }
+                    else if (y < 0 || y >= n || ++guard > n + 2) { s_stop = NN_STOP_GUARD; done = 1; }
                     else if (!done) {
                         chain[len] = y; ring[len & 255] = y;
                         if (len - 255 > ring_lo) ring_lo = len - 255;
@@ -573,6 +955,11 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__
                 zraw[4 * (int64_t)step + 1] = (double)yy;
                 zraw[4 * (int64_t)step + 2] = cur;
                 zraw[4 * (int64_t)step + 3] = (double)(nx + ny);
+            }
+            {   // every replica takes every decision: its own record of the merge, compared by k_nn_check_replicas
+                double* r = w.rec + ((int64_t)wg * NN_DMAX + (step - step0)) * 4;
+                r[0] = (double)xx; r[1] = (double)yy; r[3] = (double)(nx + ny);
+                r[2] = (inject_wrong > 0 && wg == 1 && step == inject_wrong) ? cur + 1.0 : cur;
             }
             lsize[xx] = 0;
             lsize[yy] = (uint16_t)(nx + ny);
@@ -687,6 +1074,544 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__
     if (tid == 0) {
         w.state[0] = step; w.state[1] = len; w.state[2] = top; w.state[3] = second; w.state[4] = first_ptr;
         w.state[5] = s_stop; w.state[6] = D;
+        w.prof[5] += c_cols; w.prof[6] += c_scans;
+        if (prof) for (int q = 0; q < 5; q++) w.prof[q] += tp[q];
+    }
+}
+
+// Every replica of k_nn_epoch_mw decides every merge itself from values that crossed workgroups through sc1 accesses
+// (measured behaviour, not an architectural guarantee: MI355X_MICROARCH.md).  A stale read would show up as replicas
+// that disagree - so their records of the epoch are compared, and a difference stops the chain with an error
+// instead of returning a wrong tree.
+__global__ __launch_bounds__(256) void k_nn_check_replicas(NNWorkspace w, int nwg)
+{
+    if (w.state[5]) return;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int count = w.state[0] - w.state[9];
+    if (k >= count || k >= NN_DMAX) return;
+    const unsigned long long* r0 = reinterpret_cast<const unsigned long long*>(w.rec + (int64_t)k * 4);
+    bool same = true;
+    for (int g = 1; g < nwg; g++) {
+        const unsigned long long* rg = reinterpret_cast<const unsigned long long*>(w.rec + ((int64_t)g * NN_DMAX + k) * 4);
+        same = same && rg[0] == r0[0] && rg[1] == r0[1] && rg[2] == r0[2] && rg[3] == r0[3];
+    }
+    if (!same) atomicCAS(&w.state[5], 0, NN_STOP_DIVERGED);
+}
+
+// ---- column slices AND the neighbour cache: k_nn_epoch_mwc ---------------------------------------------------------
+// A lone CU ingests a row at ~55-77 GB/s whatever the loop looks like (the limit is the CU's outstanding misses), so
+// with the scans the cache leaves (~1.3 per merge) and the update, a merge on one workgroup still streams ~3.7 rows.
+// Here NWG workgroups are replicas of ONE state machine, as in k_nn_epoch_mw: each streams its column slice only.
+// On top of that:
+//  * the neighbour cache (nnidx, tie flags) is replicated in every workgroup's LDS and kept identical: scan results
+//    and the merged row's minimum arrive through the exchanges; "neighbour merged -> unknown" is applied by every
+//    replica to all rows; the one change only a slice's owner can see - a merged cluster landing AT OR BELOW a row's
+//    cached minimum - is signalled by a flag in the owner's message and answered by every replica dropping the cache
+//    entries of that whole slice (rare: exact ties or an fp-rounding fluke; costs scans, never correctness).
+//    Cached distances (nnval) are private to the owner of the column: nobody else reads them.
+//  * the scan that follows almost every merge - the new chain top `a`, whose neighbour was one of the merged pair -
+//    is FUSED into the update pass: the pass streams rows x, y and a together; d(a, y') is the element of the new row
+//    that the owner of column a computes anyway, so the hand-off slot of k_nn_epoch_mw is not needed, and one
+//    exchange carries both the merged row's minimum and row a's.
+// Per merge: ~1.3 passes over a slice and ~1.3 exchanges (k_nn_epoch_mw: 3.9 passes, 2.9 exchanges).
+#define NN_LD16(reg, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(reg) : "v"(ptr) : "memory")
+#define NN_DRAIN8(a, b, c, d, e, f, g, h) \
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)::"memory")
+
+#define NN_LD8_SC1(reg, ptr) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(reg) : "v"(ptr) : "memory")
+#define NN_LD8(reg, ptr) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(reg) : "v"(ptr) : "memory")
+#define NN_DRAIN6(a, b, c, d, e, f) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f)::"memory")
+__device__ __forceinline__ double nn_f64(unsigned long long bits) { return __longlong_as_double((long long)bits); }
+
+//   {value bits 31..0, seq} {value bits 63..32, index (17 bits) | tie << 17 | event << 18 | (seq & 0x1fff) << 19}
+__device__ __forceinline__ u32x4 mwc_pack(double v, int idx, int tie, int ev, unsigned int seq)
+{
+    u32x4 p;
+    p.x = (unsigned int)__double2loint(v); p.y = seq;
+    p.z = (unsigned int)__double2hiint(v);
+    p.w = ((unsigned int)((idx >= 0 && idx < 0x1ffff) ? idx : 0x1ffff)) | ((unsigned int)(tie ? 1 : 0) << 17) |
+          ((unsigned int)(ev ? 1 : 0) << 18) | ((seq & 0x1fffu) << 19);
+    return p;
+}
+__device__ __forceinline__ bool mwc_ready(u32x4 p, unsigned int seq) { return p.y == seq && (p.w >> 19) == (seq & 0x1fffu); }
+__device__ __forceinline__ int mwc_index(u32x4 p) { const int i = (int)(p.w & 0x1ffffu); return i == 0x1ffff ? 0x7fffffff : i; }
+__device__ __forceinline__ int mwc_tie(u32x4 p) { return (int)((p.w >> 17) & 1u); }
+__device__ __forceinline__ int mwc_event(u32x4 p) { return (int)((p.w >> 18) & 1u); }
+
+static constexpr int NN_MWC_MAX = 32768;                 // sizes + cache of every column in the LDS of every replica
+
+template <int NWG>
+__global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict__ W, int64_t ld, int n,
+                                                             int* __restrict__ chain_all, double* __restrict__ zraw,
+                                                             NNWorkspace w, int dcap, int total_steps)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_nn[];
+    const int nwords = (n + 31) >> 5, nw4 = (nwords + 3) & ~3, n2 = (n + 7) & ~7;
+    uint32_t* alive = reinterpret_cast<uint32_t*>(smem_nn);
+    uint32_t* smask = alive + nw4;
+    uint32_t* tieb = smask + nw4;
+    uint16_t* lsize = reinterpret_cast<uint16_t*>(tieb + nw4);
+    uint16_t* nnidx = lsize + n2;
+    __shared__ int dslot[NN_DMAX], dtime[NN_DMAX];
+    __shared__ double s_v[32];
+    __shared__ int s_i[32], s_t[32];
+    __shared__ int ring[256];
+    __shared__ double s_dprev, s_my_v, s_a_v;
+    __shared__ int s_x, s_prev, s_act, s_stop, s_mx, s_my, s_nx, s_ny, s_tx, s_ty, s_ey, s_a, s_ta, s_ev, s_evmask, s_my_i, s_my_t,
+        s_a_i, s_a_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
+    int* __restrict__ chain = chain_all + (int64_t)wg * (n + 2);           // every workgroup keeps its own copy
+    u32x4* mail = reinterpret_cast<u32x4*>(w.mail);
+    int step = w.state[0];
+    if (step >= total_steps || w.state[5]) {
+        if (tid == 0 && wg == 0) w.state[6] = 0;
+        return;
+    }
+    // column slice of this workgroup: multiples of 64 so that mask words and 16-byte loads never straddle
+    const int slice = (((n + NWG - 1) / NWG) + 63) & ~63;
+    const int c0 = wg * slice < n ? wg * slice : n;
+    const int c1 = c0 + slice < n ? c0 + slice : n;
+    for (int i = tid; i < nwords; i += NN_THREADS) { alive[i] = w.alive[i]; smask[i] = w.alive[i]; tieb[i] = 0u; }
+    __syncthreads();
+    for (int i = tid; i < n; i += NN_THREADS) {
+        lsize[i] = w.size[i];
+        const uint32_t c = w.nnc[i];
+        nnidx[i] = (uint16_t)(c & 0xffffu);
+        if (c >> 16) atomicOr(&tieb[i >> 5], 1u << (i & 31));
+    }
+    int len = w.state[1], top = w.state[2], second = w.state[3], first_ptr = w.state[4];
+    if (tid == 0) { s_stop = 0; s_ev = 0; }
+    const int* __restrict__ chain0 = chain_all;             // chain prefix of the earlier epochs: workgroup 0's copy
+    // the top of the saved chain goes into the LDS ring right away: pops must not wait for global memory
+    int ring_lo = len > 256 ? len - 256 : 0;
+    if (tid < 256 && ring_lo + tid < len) ring[(ring_lo + tid) & 255] = chain0[ring_lo + tid];
+    __syncthreads();
+    int D = 0;
+    uint32_t xbit = 0u;
+    unsigned int xseq = 0u;                                  // exchanges so far (uniform)
+    unsigned long long tp[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+    const bool prof = w.state[8] != 0 && wg == 0 && tid == 0;
+    int lowmark = len;                                       // lane 0: chain entries below this are still the earlier epochs'
+    const int step0 = step;
+    const int inject_late = w.state[10], inject_wrong = w.state[11];      // test hooks (0 = off)
+    unsigned long long c_cols = 0, c_scans = 0, c_hits = 0;
+    if (tid == 0 && wg == 0) w.state[9] = step0;
+    int guard = 0, stop_code = 0;                            // lane 0
+    bool stopped = false;                                    // uniform
+
+    for (; step < total_steps && D < dcap; step++) {
+        if (prof) t0 = wall_clock64();
+        while (true) {
+            // ---- walk the chain on cached neighbours (lane 0 of every replica, identical state -> identical walk)
+            if (tid == 0) {
+                if (len == 0) {
+                    while (first_ptr < n && !((alive[first_ptr >> 5] >> (first_ptr & 31)) & 1u)) first_ptr++;
+                    chain[0] = first_ptr; ring[0] = first_ptr; ring_lo = 0; top = first_ptr; second = -1; len = 1; lowmark = 0;
+                }
+                int act = 0;                                 // 1: scan row `top`, 2: merge (top, second), 3: stop
+                while (act == 0) {
+                    const int x = top, prev = (len > 1) ? second : -1;
+                    const uint32_t idx = nnidx[x];
+                    if (idx == NN_NOIDX) act = 1;
+                    else if ((int)idx == prev) act = 2;
+                    else if (prev >= 0 && ((tieb[x >> 5] >> (x & 31)) & 1u)) act = 1;
+                    else if (++guard > 4 * n + 8) { stop_code = NN_STOP_GUARD; act = 3; }
+                    else {
+                        chain[len] = (int)idx; ring[len & 255] = (int)idx;
+                        if (len - 255 > ring_lo) ring_lo = len - 255;
+                        second = top; top = (int)idx; len++;
+                        c_hits++;
+                    }
+                }
+                s_act = act; s_x = top; s_prev = (len > 1) ? second : -1; s_tx = -1;
+                if (act == 1) {
+                    xbit = smask[top >> 5] & (1u << (top & 31));
+                    smask[top >> 5] &= ~xbit;
+                    c_scans++; c_cols += (unsigned long long)(total_steps + 1 - step);
+                }
+            }
+            __syncthreads();
+            if (s_act != 1) break;
+            // ---- a scan on its own: this slice of row x, then one exchange
+            const int x = s_x, prev = s_prev;
+            if (tid < D && dslot[tid] == x) s_tx = dtime[tid];
+            __syncthreads();
+            if (prof) { t1 = wall_clock64(); tp[0] += t1 - t0; t0 = t1; }
+            const int tx = s_tx;
+            const double* __restrict__ rowx = W + (int64_t)x * ld;
+            // every load is ISSUED before anything waits: the gathered ones (d(x, prev), the dirty partners' values from
+            // whichever row is the authoritative one) and the streamed slice are in flight together
+            unsigned long long r_dp = 0, r_cv = 0;
+            const bool want_dp = tid == 64 && prev >= 0 && ((smask[prev >> 5] >> (prev & 31)) & 1u);
+            if (want_dp) NN_LD8_SC1(r_dp, rowx + prev);
+            int cd = -1; bool cmine = false;
+            if (tid < D) {
+                const int d = dslot[tid];
+                if (d >= 0 && d != x && ((alive[d >> 5] >> (d & 31)) & 1u)) {
+                    cmine = d >= c0 && d < c1;
+                    if (cmine || d == prev) {
+                        cd = d;
+                        const double* src = dtime[tid] > tx ? W + (int64_t)d * ld + x : rowx + d;
+                        NN_LD8_SC1(r_cv, src);
+                    }
+                }
+            }
+            ArgMinT best = {__builtin_inf(), 0x7fffffff, 0};
+            ArgMinT cand = {__builtin_inf(), 0x7fffffff, 0};
+            for (int j0 = c0 + tid * 2; j0 < c1; j0 += 4 * NN_THREADS) {    // two 16-byte loads in flight per lane
+                const int j1 = j0 + 2 * NN_THREADS;
+                const bool two = j1 < c1;
+                u32x4 r0, r1;
+                NN_LD16_SC1(r0, rowx + j0);
+                NN_LD16_SC1(r1, rowx + (two ? j1 : j0));
+                NN_DRAIN2(r0, r1);
+                {
+                    const double2 v = mw_pair(r0);
+                    const uint32_t bits = smask[j0 >> 5] >> (j0 & 31);
+                    if ((bits & 1u) && v.x <= best.v) { if (v.x < best.v) { best.v = v.x; best.i = j0; best.t = 0; } else best.t = 1; }
+                    if ((bits & 2u) && v.y <= best.v) { if (v.y < best.v) { best.v = v.y; best.i = j0 + 1; best.t = 0; } else best.t = 1; }
+                }
+                if (two) {
+                    const double2 v = mw_pair(r1);
+                    const uint32_t bits = smask[j1 >> 5] >> (j1 & 31);
+                    if ((bits & 1u) && v.x <= best.v) { if (v.x < best.v) { best.v = v.x; best.i = j1; best.t = 0; } else best.t = 1; }
+                    if ((bits & 2u) && v.y <= best.v) { if (v.y < best.v) { best.v = v.y; best.i = j1 + 1; best.t = 0; } else best.t = 1; }
+                }
+            }
+            NN_DRAIN2(r_dp, r_cv);
+            if (want_dp) s_dprev = nn_f64(r_dp);
+            if (cd >= 0) {
+                const double v = nn_f64(r_cv);
+                if (cmine) { cand.v = v; cand.i = cd; }
+                if (cd == prev) s_dprev = v;
+            }
+            if (cand.i != 0x7fffffff) best = argmint_join(best, cand.v, cand.i, 0);
+            best = argmint_wave(best);
+            if (lane == 0) { s_v[wave] = best.v; s_i[wave] = best.i; s_t[wave] = best.t; }
+            __syncthreads();
+            if (prof) { t1 = wall_clock64(); tp[1] += t1 - t0; t0 = t1; }
+            xseq++;
+            if (wave == 0) {
+                ArgMinT m = {lane < 16 ? s_v[lane] : __builtin_inf(), lane < 16 ? s_i[lane] : 0x7fffffff, lane < 16 ? s_t[lane] : 0};
+                m = argmint_row16(m);                               // this slice's result, in every lane of row 0
+                u32x4* slots = mail + (xseq & 1u) * (NN_MAXWG * 2);
+                if (lane == 0) st16_sc1(slots + wg * 2, mwc_pack(m.v, m.i, m.t, 0, xseq));
+                ArgMinT o = {__builtin_inf(), 0x7fffffff, 0};
+                int late = 0;
+                if (lane < NWG) {
+                    if (lane == wg) o = m;
+                    else {
+                        u32x4 r = ld16_sc1(slots + lane * 2);
+                        int budget = 1000000;
+                        while (!mwc_ready(r, xseq) && --budget > 0) { __builtin_amdgcn_s_sleep(1); r = ld16_sc1(slots + lane * 2); }
+                        if (!mwc_ready(r, xseq)) late = 1;
+                        o.v = mw_value(r); o.i = mwc_index(r); o.t = mwc_tie(r);
+                    }
+                }
+                if (inject_late > 0 && (int)xseq == inject_late) late = 1;      // test hook: a peer that never answers
+                late = __any(late);
+                m = argmint_row16(o);
+                if (lane == 0) {
+                    smask[x >> 5] |= xbit;
+                    if (late) { s_stop = NN_STOP_LATE; stop_code = NN_STOP_LATE; }
+                    else if (m.i < 0 || m.i >= n) { s_stop = NN_STOP_GUARD; stop_code = NN_STOP_GUARD; }
+                    else {
+                        nnidx[x] = (uint16_t)m.i;
+                        if (m.t) tieb[x >> 5] |= (1u << (x & 31)); else tieb[x >> 5] &= ~(1u << (x & 31));
+                        if (x >= c0 && x < c1) w.nnval[x] = m.v;        // the owner of column x keeps the distance
+                        int y = m.i;
+                        if (prev >= 0 && !(m.v < s_dprev)) y = prev;    // SciPy: the previous element wins unless STRICTLY closer
+                        if (y != prev) {
+                            if (++guard > 4 * n + 8) { s_stop = NN_STOP_GUARD; stop_code = NN_STOP_GUARD; }
+                            chain[len] = y; ring[len & 255] = y;
+                            if (len - 255 > ring_lo) ring_lo = len - 255;
+                            second = top; top = y; len++;
+                        } else nnidx[x] = (uint16_t)prev;               // reciprocal by the tie rule: let the walk see it
+                    }
+                }
+            }
+            __syncthreads();
+            if (prof) { t1 = wall_clock64(); tp[2] += t1 - t0; t0 = t1; }
+            if (s_stop) { stopped = true; break; }
+        }
+        if (stopped || s_act == 3) break;
+        // ---- merge (top, second); the row the chain returns to - `a` - is scanned in the same pass if it needs it
+        if (tid == 0) {
+            int xx = top, yy = second;
+            len -= 2;
+            if (xx > yy) { int t = xx; xx = yy; yy = t; }
+            int nx = lsize[xx], ny = lsize[yy];
+            lsize[xx] = 0;
+            lsize[yy] = (uint16_t)(nx + ny);
+            alive[xx >> 5] &= ~(1u << (xx & 31));
+            smask[xx >> 5] &= ~(1u << (xx & 31));
+            s_mx = xx; s_my = yy; s_nx = nx; s_ny = ny; s_tx = -1; s_ty = -1; s_ey = -1; s_ta = -1;
+            // entries no push of this epoch has overwritten live in workgroup 0's copy (saved by the last epoch)
+            if (len < lowmark) lowmark = len;
+            const int i1 = len - 1, i2 = len - 2;
+            top = len >= 1 ? (i1 >= ring_lo ? ring[i1 & 255] : (i1 < lowmark ? chain0[i1] : chain[i1])) : -1;
+            second = len >= 2 ? (i2 >= ring_lo ? ring[i2 & 255] : (i2 < lowmark ? chain0[i2] : chain[i2])) : -1;
+            int a = -1;
+            if (top >= 0) {
+                const uint32_t ia = nnidx[top];
+                if (ia == NN_NOIDX || (int)ia == xx || (int)ia == yy) a = top;
+            }
+            s_a = a; s_prev = (a >= 0 && len > 1) ? second : -1;
+            if (a >= 0) { c_scans++; c_cols += (unsigned long long)(total_steps - step); }
+        }
+        __syncthreads();
+        const int mx = s_mx, my = s_my, a = s_a, aprev = s_prev;
+        if (tid < D) {
+            if (dslot[tid] == mx) s_tx = dtime[tid];
+            if (dslot[tid] == my) { s_ty = dtime[tid]; s_ey = tid; }
+            if (dslot[tid] == a) s_ta = dtime[tid];
+        }
+        __syncthreads();
+        if (prof) { t1 = wall_clock64(); tp[3] += t1 - t0; t0 = t1; }
+        {
+            const int tmx = s_tx, tmy = s_ty, ta = s_ta;
+            const double fx = (double)s_nx, fy = (double)s_ny, fs = (double)(s_nx + s_ny);
+            const double rcp = 1.0 / fs;
+            const double* __restrict__ rx = W + (int64_t)mx * ld;
+            double* __restrict__ ry = W + (int64_t)my * ld;
+            const double* __restrict__ ra = W + (int64_t)(a >= 0 ? a : mx) * ld;
+            // ---- issue every gathered load (nothing waits yet)
+            unsigned long long r_h = 0, r_dp = 0, r_dxi = 0, r_dyi = 0, r_nvd = 0, r_av = 0;
+            // the merge height d(x, y): the row of whichever cluster merged last is the authoritative one
+            if (tid == NN_THREADS - 1) { const double* src = tmx > tmy ? rx + my : ry + mx; NN_LD8_SC1(r_h, src); }
+            const bool want_dp = tid == 64 && aprev >= 0 && ((smask[aprev >> 5] >> (aprev & 31)) & 1u);
+            if (want_dp) NN_LD8_SC1(r_dp, ra + aprev);
+            int dd = -1, ad = -1;                                // dirty partner this lane updates / offers to row a's scan
+            bool amine = false;
+            if (tid < D) {
+                const int d = dslot[tid];
+                if (d >= 0 && d != my && ((alive[d >> 5] >> (d & 31)) & 1u)) {
+                    const bool mine = d >= c0 && d < c1;
+                    if (mine) {                                      // columns of this slice only: rx[d], ry[d] are its own
+                        dd = d;
+                        const double* sx = dtime[tid] > tmx ? W + (int64_t)d * ld + mx : rx + d;
+                        const double* sy = dtime[tid] > tmy ? W + (int64_t)d * ld + my : ry + d;
+                        NN_LD8_SC1(r_dxi, sx);
+                        NN_LD8_SC1(r_dyi, sy);
+                        NN_LD8(r_nvd, w.nnval + d);
+                    }
+                    if (a >= 0 && d != a && (mine || d == aprev)) {
+                        ad = d; amine = mine;
+                        const double* sa = dtime[tid] > ta ? W + (int64_t)d * ld + a : ra + d;
+                        NN_LD8_SC1(r_av, sa);
+                    }
+                }
+            }
+            ArgMinT rbest = {__builtin_inf(), 0x7fffffff, 0};   // this slice of the new row: the merged cluster's cache entry
+            ArgMinT abest = {__builtin_inf(), 0x7fffffff, 0};   // this slice of row a: the streamed columns (ascending per lane)
+            ArgMinT acand = {__builtin_inf(), 0x7fffffff, 0};   // ... and its gathered candidates (dirty partners, the new cluster)
+            int ev = 0;                                         // a cached minimum of this slice was reached or undercut
+            bool first = true;
+            for (int j0 = c0 + tid * 2; j0 < c1 || first; j0 += 4 * NN_THREADS) {
+                const bool any = j0 < c1;
+                const int j1 = j0 + 2 * NN_THREADS;
+                const bool two = any && j1 < c1;
+                const int ja = any ? j0 : 0, jb = two ? j1 : ja;       // lanes without a pair re-read column 0 (always in bounds)
+                u32x4 ra0, rb0, rc0, rn0, ra1, rb1, rc1, rn1;
+                NN_LD16_SC1(ra0, rx + ja);
+                NN_LD16_SC1(rb0, ry + ja);
+                NN_LD16_SC1(rc0, ra + ja);
+                NN_LD16(rn0, w.nnval + ja);
+                NN_LD16_SC1(ra1, rx + jb);
+                NN_LD16_SC1(rb1, ry + jb);
+                NN_LD16_SC1(rc1, ra + jb);
+                NN_LD16(rn1, w.nnval + jb);
+                if (first) {
+                    // while the loads are in flight: every replica drops "my neighbour is x or y" for the rows outside its
+                    // slice (LDS only; the own slice is handled with the streamed / gathered values below)
+                    for (int i = tid * 2; i < n; i += 2 * NN_THREADS) {
+                        if (i >= c0 && i < c1) continue;
+                        const uint32_t ip = *reinterpret_cast<const uint32_t*>(nnidx + i);
+                        const uint32_t i0 = ip & 0xffffu, i1 = ip >> 16;
+                        if (i0 == (uint32_t)mx || i0 == (uint32_t)my) nnidx[i] = (uint16_t)NN_NOIDX;
+                        if (i1 == (uint32_t)mx || i1 == (uint32_t)my) nnidx[i + 1] = (uint16_t)NN_NOIDX;
+                    }
+                }
+                NN_DRAIN8(ra0, rb0, rc0, rn0, ra1, rb1, rc1, rn1);
+                first = false;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if ((h == 0 && !any) || (h == 1 && !two)) continue;
+                    const int j = h ? j1 : j0;
+                    const double2 xa = mw_pair(h ? ra1 : ra0);
+                    double2 b = mw_pair(h ? rb1 : rb0);
+                    const double2 va = mw_pair(h ? rc1 : rc0);
+                    const double2 nv = mw_pair(h ? rn1 : rn0);
+                    const uint32_t bits = smask[j >> 5] >> (j & 31);
+                    const uint32_t ip = *reinterpret_cast<const uint32_t*>(nnidx + j);
+                    const bool w0 = (bits & 1u) && j != my, w1 = (bits & 2u) && j + 1 != my;
+                    if (w0) {
+                        b.x = div_by_small_int(fx * xa.x + fy * b.x, fs, rcp);
+                        if (b.x <= rbest.v) { if (b.x < rbest.v) { rbest.v = b.x; rbest.i = j; rbest.t = 0; } else rbest.t = 1; }
+                        const uint32_t id = ip & 0xffffu;
+                        if (id == (uint32_t)mx || id == (uint32_t)my) nnidx[j] = (uint16_t)NN_NOIDX;
+                        else if (id != NN_NOIDX && b.x <= nv.x) ev = 1;
+                        if (a >= 0) {
+                            if (j == a) acand = argmint_join(acand, b.x, my, 0);          // d(a, y'), computed a moment ago
+                            else if (va.x <= abest.v) { if (va.x < abest.v) { abest.v = va.x; abest.i = j; abest.t = 0; } else abest.t = 1; }
+                        }
+                    }
+                    if (w1) {
+                        b.y = div_by_small_int(fx * xa.y + fy * b.y, fs, rcp);
+                        if (b.y <= rbest.v) { if (b.y < rbest.v) { rbest.v = b.y; rbest.i = j + 1; rbest.t = 0; } else rbest.t = 1; }
+                        const uint32_t id = ip >> 16;
+                        if (id == (uint32_t)mx || id == (uint32_t)my) nnidx[j + 1] = (uint16_t)NN_NOIDX;
+                        else if (id != NN_NOIDX && b.y <= nv.y) ev = 1;
+                        if (a >= 0) {
+                            if (j + 1 == a) acand = argmint_join(acand, b.y, my, 0);
+                            else if (va.y <= abest.v) { if (va.y < abest.v) { abest.v = va.y; abest.i = j + 1; abest.t = 0; } else abest.t = 1; }
+                        }
+                    }
+                    // a pair store must not carry the OLD value of a dirty column (its own 8-byte store, below, is not ordered
+                    // against this one): elements that were not recomputed are left alone
+                    if (w0 && w1) {
+                        u32x4 pk;
+                        pk.x = (unsigned int)__double2loint(b.x); pk.y = (unsigned int)__double2hiint(b.x);
+                        pk.z = (unsigned int)__double2loint(b.y); pk.w = (unsigned int)__double2hiint(b.y);
+                        st16_sc1(ry + j, pk);
+                    }
+                    else if (w0) st8_sc1(ry + j, b.x);
+                    else if (w1) st8_sc1(ry + j + 1, b.y);
+                }
+            }
+            // ---- the gathered values: dirty partners of the update, candidates of row a's scan
+            NN_DRAIN6(r_h, r_dp, r_dxi, r_dyi, r_nvd, r_av);
+            if (want_dp) s_dprev = nn_f64(r_dp);
+            if (dd >= 0) {
+                const double dv = div_by_small_int(fx * nn_f64(r_dxi) + fy * nn_f64(r_dyi), fs, rcp);
+                st8_sc1(ry + dd, dv);
+                rbest = argmint_join(rbest, dv, dd, 0);
+                const uint32_t id = nnidx[dd];
+                if (id == (uint32_t)mx || id == (uint32_t)my) nnidx[dd] = (uint16_t)NN_NOIDX;
+                else if (id != NN_NOIDX && dv <= nn_f64(r_nvd)) ev = 1;
+                if (dd == a) acand = argmint_join(acand, dv, my, 0);        // d(a, y') for the scan of row a
+            }
+            if (ad >= 0) {
+                const double v = nn_f64(r_av);
+                if (amine) acand = argmint_join(acand, v, ad, 0);
+                if (ad == aprev) s_dprev = v;
+            }
+            if (ev) s_ev = 1;
+            if (acand.i != 0x7fffffff) abest = argmint_join(abest, acand.v, acand.i, acand.t);
+            rbest = argmint_wave(rbest);
+            abest = argmint_wave(abest);
+            if (lane == 0) { s_v[wave] = rbest.v; s_i[wave] = rbest.i; s_t[wave] = rbest.t; s_v[16 + wave] = abest.v; s_i[16 + wave] = abest.i; s_t[16 + wave] = abest.t; }
+            if (tid == NN_THREADS - 1) {
+                const double height = nn_f64(r_h);
+                if (wg == 0) {
+                    zraw[4 * (int64_t)step + 0] = (double)mx; zraw[4 * (int64_t)step + 1] = (double)my;
+                    zraw[4 * (int64_t)step + 2] = height; zraw[4 * (int64_t)step + 3] = fs;
+                }
+                double* r = w.rec + ((int64_t)wg * NN_DMAX + (step - step0)) * 4;   // this replica's record of the merge
+                r[0] = (double)mx; r[1] = (double)my; r[3] = fs;
+                r[2] = (inject_wrong > 0 && wg == 1 && step == inject_wrong) ? height + 1.0 : height;
+            }
+            // the stores above are inline assembly the compiler's wait-count pass does not see: every storing wave drains
+            // them before the barrier behind which the exchange signals
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (prof) { t1 = wall_clock64(); tp[4] += t1 - t0; t0 = t1; }
+            // ---- one exchange: the merged row's minimum (+ event flag) and row a's minimum
+            xseq++;
+            if (wave == 0) {
+                ArgMinT m = {lane < 32 ? s_v[lane] : __builtin_inf(), lane < 32 ? s_i[lane] : 0x7fffffff, lane < 32 ? s_t[lane] : 0};
+                m = argmint_row16(m);                               // lanes 0-15: new row, lanes 16-31: row a (this slice)
+                u32x4* slots = mail + (xseq & 1u) * (NN_MAXWG * 2);
+                if (lane == 0) st16_sc1(slots + wg * 2, mwc_pack(m.v, m.i, m.t, s_ev, xseq));
+                if (lane == 16) st16_sc1(slots + wg * 2 + 1, mwc_pack(m.v, m.i, m.t, 0, xseq));
+                ArgMinT o = {__builtin_inf(), 0x7fffffff, 0};
+                int late = 0, evbit = 0;
+                const int peer = lane & 15, which = lane >> 4;      // which: 0 = new row, 1 = row a
+                if (lane < 32 && peer < NWG) {
+                    if (peer == wg) { o = m; evbit = which == 0 ? s_ev : 0; }
+                    else {
+                        u32x4 r = ld16_sc1(slots + peer * 2 + which);
+                        int budget = 1000000;
+                        while (!mwc_ready(r, xseq) && --budget > 0) { __builtin_amdgcn_s_sleep(1); r = ld16_sc1(slots + peer * 2 + which); }
+                        if (!mwc_ready(r, xseq)) late = 1;
+                        o.v = mw_value(r); o.i = mwc_index(r); o.t = mwc_tie(r);
+                        evbit = which == 0 ? mwc_event(r) : 0;
+                    }
+                }
+                if (inject_late > 0 && (int)xseq == inject_late) late = 1;
+                late = __any(late);
+                const unsigned long long evm = __ballot(evbit != 0);
+                m = argmint_row16(o);
+                const double av = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m.v), 16), __builtin_amdgcn_readlane(__double2loint(m.v), 16));
+                const int ai = __builtin_amdgcn_readlane(m.i, 16), at = __builtin_amdgcn_readlane(m.t, 16);
+                if (lane == 0) {
+                    if (late) { s_stop = NN_STOP_LATE; stop_code = NN_STOP_LATE; }
+                    s_evmask = (int)(evm & 0xffffull);
+                    s_my_v = m.v; s_my_i = m.i; s_my_t = m.t;
+                    s_a_v = av; s_a_i = ai; s_a_t = at;
+                    s_ev = 0;
+                }
+            }
+            __syncthreads();
+            if (s_stop) { stopped = true; break; }
+            const int evmask = s_evmask;
+            if (evmask) {                                          // rare: whole slices lose their cache entries
+                for (int g = 0; g < NWG; g++) {
+                    if (!((evmask >> g) & 1)) continue;
+                    const int g0 = g * slice < n ? g * slice : n, g1 = g0 + slice < n ? g0 + slice : n;
+                    for (int i = g0 + tid; i < g1; i += NN_THREADS) nnidx[i] = (uint16_t)NN_NOIDX;
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                // cluster y is dirty from now on; its neighbour is known
+                if (s_ey >= 0) dslot[s_ey] = -1;
+                dslot[D] = my; dtime[D] = step;
+                smask[my >> 5] &= ~(1u << (my & 31));
+                if (s_my_i >= 0 && s_my_i < n) {
+                    nnidx[my] = (uint16_t)s_my_i;
+                    if (s_my_t) tieb[my >> 5] |= (1u << (my & 31)); else tieb[my >> 5] &= ~(1u << (my & 31));
+                    if (my >= c0 && my < c1) w.nnval[my] = s_my_v;
+                } else nnidx[my] = (uint16_t)NN_NOIDX;
+                if (a >= 0) {                                      // the fused scan of row a: same decision as a scan on its own
+                    if (s_a_i < 0 || s_a_i >= n) { s_stop = NN_STOP_GUARD; stop_code = NN_STOP_GUARD; }
+                    else {
+                        nnidx[a] = (uint16_t)s_a_i;
+                        if (s_a_t) tieb[a >> 5] |= (1u << (a & 31)); else tieb[a >> 5] &= ~(1u << (a & 31));
+                        if (a >= c0 && a < c1) w.nnval[a] = s_a_v;
+                        int y = s_a_i;
+                        if (aprev >= 0 && !(s_a_v < s_dprev)) y = aprev;
+                        if (y != aprev) {
+                            if (++guard > 4 * n + 8) { s_stop = NN_STOP_GUARD; stop_code = NN_STOP_GUARD; }
+                            chain[len] = y; ring[len & 255] = y;
+                            if (len - 255 > ring_lo) ring_lo = len - 255;
+                            second = top; top = y; len++;
+                        } else nnidx[a] = (uint16_t)aprev;
+                    }
+                }
+            }
+            D++;
+        }
+        __syncthreads();
+        if (s_stop) break;
+        if (prof) { t1 = wall_clock64(); tp[2] += t1 - t0; }
+    }
+    __syncthreads();
+    if (wg != 0) return;
+    for (int i = tid; i < nwords; i += NN_THREADS) w.alive[i] = alive[i];
+    for (int i = tid; i < n; i += NN_THREADS) {
+        w.size[i] = lsize[i]; w.gtime[i] = -1;
+        w.nnc[i] = (uint32_t)nnidx[i] | (((tieb[i >> 5] >> (i & 31)) & 1u) << 16);
+    }
+    __syncthreads();
+    if (tid < D) { w.dslot[tid] = dslot[tid]; w.dtime[tid] = dtime[tid]; }
+    __syncthreads();
+    if (tid < D && dslot[tid] >= 0) w.gtime[dslot[tid]] = dtime[tid];
+    if (tid == 0) {
+        w.state[0] = step; w.state[1] = len; w.state[2] = top; w.state[3] = second; w.state[4] = first_ptr;
+        w.state[5] = stop_code; w.state[6] = D;
+        w.prof[5] += c_cols; w.prof[6] += c_scans; w.prof[7] += c_hits;
         if (prof) for (int q = 0; q < 5; q++) w.prof[q] += tp[q];
     }
 }
@@ -751,10 +1676,18 @@ __global__ __launch_bounds__(1024) void k_nn_remap(NNWorkspace w, int n_cur, int
     // and a write never lands beyond the chunk being processed (new index <= old index)
     for (int c0i = 0; c0i < n_cur; c0i += 1024) {
         const int i = c0i + tid;
-        int nw = -1; uint16_t sz = 0; int og = 0;
-        if (i < n_cur) { nw = w.newidx[i]; sz = w.size[i]; og = w.orig[i]; }
+        int nw = -1; uint16_t sz = 0; int og = 0; uint32_t cc = NN_NOIDX; double cv = 0.0;
+        if (i < n_cur) { nw = w.newidx[i]; sz = w.size[i]; og = w.orig[i]; cc = w.nnc[i]; cv = w.nnval[i]; }
         __syncthreads();
-        if (nw >= 0) { w.size[nw] = sz; w.orig[nw] = og; }
+        if (nw >= 0) {
+            w.size[nw] = sz; w.orig[nw] = og;
+            // neighbour cache: the cached slot moves with its cluster (a live row never caches a dead slot while the
+            // cache is in use; epochs that do not maintain it leave stale entries, which are rebuilt before use)
+            const uint32_t id = cc & 0xffffu;
+            const int nid = (id != NN_NOIDX && (int)id < n_cur) ? w.newidx[id] : -1;
+            w.nnc[nw] = nid >= 0 ? ((uint32_t)nid | (cc & 0x10000u)) : NN_NOIDX;
+            w.nnval[nw] = cv;
+        }
         __syncthreads();
     }
     const int len = w.state[1];
@@ -794,26 +1727,38 @@ __global__ __launch_bounds__(256) void k_nn_translate(double* __restrict__ zraw,
 }
 
 // W and W2: two n x ldw buffers (W holds the distances on entry; both are scratch afterwards).
-// Returns the number of k_nn_epoch launches.
+// Returns the number of epoch launches.  force_single: never the column-sliced kernel (the retry after a late peer).
 int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double* zraw, void* workspace, bool profile,
-                   int dcap, bool compact, hipStream_t s)
+                   int dcap, bool compact, bool force_single, hipStream_t s)
 {
     int epochs = 0;
     NNWorkspace w = carve(workspace, n);
     // Column-sliced chain on several workgroups (k_nn_epoch_mw): its fixed cost per scan (one exchange) is paid back
-    // by the shorter streams from about 16k live columns on (12.5 us per merge at 16k either way; at 32k 18.8 -> 12.8).
-    // HICMI_NNCHAIN_WGS = 1, 2, 4 or 8 forces a width for every epoch (tests, A/B).
-    const char* wgs_text = getenv("HICMI_NNCHAIN_WGS");
+    // by the shorter streams from about 20k live columns on.  HICMI_NNCHAIN_WGS = 1, 2, 4 or 8 forces a width for
+    // every epoch (tests, A/B).  Narrower epochs run on one workgroup with the neighbour cache (k_nn_epoch_nc);
+    // HICMI_NNCHAIN_PLAIN=1 selects the cache-less k_nn_epoch instead (A/B, and the reference point of the tests).
+    const char* wgs_text = force_single ? "1" : getenv("HICMI_NNCHAIN_WGS");
     const int wgs_env = wgs_text ? atoi(wgs_text) : 0;
     const int wgs = wgs_text ? (wgs_env >= 8 ? 8 : (wgs_env >= 4 ? 4 : (wgs_env >= 2 ? 2 : 1))) : 8;
-    const int mw_from = wgs_text ? 64 * wgs : 20000;          // live columns from which an epoch runs sliced
+    const char* from_text = getenv("HICMI_NNCHAIN_MW_FROM");
+    const int mw_from = wgs_text ? 64 * wgs : (from_text ? atoi(from_text) : 20000);   // live columns from which an epoch runs sliced
+    const bool plain = getenv("HICMI_NNCHAIN_PLAIN") != nullptr;
+    const bool fused1 = getenv("HICMI_NNCHAIN_FUSED1") != nullptr;       // narrow epochs on k_nn_epoch_mwc<1> instead of k_nn_epoch_nc
+    const bool mw_old = getenv("HICMI_NNCHAIN_MW_OLD") != nullptr;       // k_nn_epoch_mw also where k_nn_epoch_mwc would fit (A/B, tests)
     if (dcap < 1) dcap = 1;
     if (dcap > NN_DMAX) dcap = NN_DMAX;
     hipLaunchKernelGGL(k_nn_init, dim3(64), dim3(256), 0, s, w, n);
     if (profile) { static const int one = 1; hipMemcpyAsync(w.state + 8, &one, sizeof(int), hipMemcpyHostToDevice, s); }
+    {
+        static int hooks[2];                                     // test hooks: see NNWorkspace::state[10], [11]
+        const char* a = getenv("HICMI_NNCHAIN_TEST_LATE"); const char* b = getenv("HICMI_NNCHAIN_TEST_DIVERGE");
+        hooks[0] = (a && !force_single) ? atoi(a) : 0; hooks[1] = b ? atoi(b) : 0;
+        if (hooks[0] || hooks[1]) hipMemcpyAsync(w.state + 10, hooks, sizeof(hooks), hipMemcpyHostToDevice, s);
+    }
     const int total_steps = n - 1;
     int n_cur = n, done = 0, interval_start = 0;
     double *cur = W, *other = W2;
+    bool cache_valid = false;                                    // w.nnval / w.nnc describe the current matrix
     {
         const int nwords = (n + 31) / 32, nw4 = (nwords + 3) & ~3;
         size_t lds_max = align16((size_t)nw4 * 8 + (size_t)n * 2);
@@ -822,18 +1767,60 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mw<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mw<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mw<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        const int nc = n < NN_NC_MAX ? n : NN_NC_MAX, ncw4 = (((nc + 31) / 32) + 3) & ~3;
+        size_t lds_nc = align16((size_t)ncw4 * 12 + (size_t)((nc + 7) & ~7) * 4);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_nc<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nc);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_nc<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nc);
+        const int mc = n < NN_MWC_MAX ? n : NN_MWC_MAX, mcw4 = (((mc + 31) / 32) + 3) & ~3;
+        size_t lds_mc = align16((size_t)mcw4 * 12 + (size_t)((mc + 7) & ~7) * 4);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mwc<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mc);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mwc<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mc);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mwc<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mc);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mwc<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mc);
     }
     while (done < total_steps) {
         const int nwords = (n_cur + 31) / 32, nw4 = (nwords + 3) & ~3;
         const size_t lds = align16((size_t)nw4 * 8 + (size_t)n_cur * 2);
-        if (profile && !(wgs_text && wgs > 1)) hipLaunchKernelGGL(k_nn_epoch<true>, dim3(1), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
-        else if (wgs > 1 && n_cur >= mw_from) {
-            hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 384, s);      // hand-off slot + mailboxes
+        const bool sliced = wgs > 1 && n_cur >= mw_from;
+        if (sliced && !plain && !mw_old && n_cur <= NN_MWC_MAX) {
+            // column slices + neighbour cache + the next scan fused into the update (k_nn_epoch_mwc)
+            if (!cache_valid) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
+            cache_valid = true;
+            const size_t lds_c = align16((size_t)nw4 * 12 + (size_t)((n_cur + 7) & ~7) * 4);
+            hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 640, s);      // mailboxes
+            if (wgs == 2) hipLaunchKernelGGL(k_nn_epoch_mwc<2>, dim3(2), dim3(NN_THREADS), lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+            else if (wgs == 4) hipLaunchKernelGGL(k_nn_epoch_mwc<4>, dim3(4), dim3(NN_THREADS), lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+            else hipLaunchKernelGGL(k_nn_epoch_mwc<8>, dim3(8), dim3(NN_THREADS), lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+            hipLaunchKernelGGL(k_nn_check_replicas, dim3((NN_DMAX + 255) / 256), dim3(256), 0, s, w, wgs);
+        }
+        else if (sliced) {
+            hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 640, s);      // hand-off slot + mailboxes
             if (wgs == 2) hipLaunchKernelGGL(k_nn_epoch_mw<2>, dim3(2), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
             else if (wgs == 4) hipLaunchKernelGGL(k_nn_epoch_mw<4>, dim3(4), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
             else hipLaunchKernelGGL(k_nn_epoch_mw<8>, dim3(8), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+            hipLaunchKernelGGL(k_nn_check_replicas, dim3((NN_DMAX + 255) / 256), dim3(256), 0, s, w, wgs);
+            cache_valid = false;
         }
-        else hipLaunchKernelGGL(k_nn_epoch<false>, dim3(1), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+        else if (!plain && fused1 && n_cur <= NN_MWC_MAX) {
+            // one workgroup, but the fused pass of k_nn_epoch_mwc (its exchange degenerates to a store nobody waits for)
+            if (!cache_valid) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
+            cache_valid = true;
+            const size_t lds_c = align16((size_t)nw4 * 12 + (size_t)((n_cur + 7) & ~7) * 4);
+            hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 640, s);
+            hipLaunchKernelGGL(k_nn_epoch_mwc<1>, dim3(1), dim3(NN_THREADS), lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+        }
+        else if (!plain && n_cur <= NN_NC_MAX) {
+            if (!cache_valid) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
+            cache_valid = true;
+            const size_t lds_nc = align16((size_t)nw4 * 12 + (size_t)((n_cur + 7) & ~7) * 4);
+            if (profile) hipLaunchKernelGGL(k_nn_epoch_nc<true>, dim3(1), dim3(NN_THREADS), lds_nc, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+            else hipLaunchKernelGGL(k_nn_epoch_nc<false>, dim3(1), dim3(NN_THREADS), lds_nc, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+        }
+        else {
+            if (profile) hipLaunchKernelGGL(k_nn_epoch<true>, dim3(1), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+            else hipLaunchKernelGGL(k_nn_epoch<false>, dim3(1), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+            cache_valid = false;
+        }
         epochs++;
         const int did = total_steps - done < dcap ? total_steps - done : dcap;
         done += did;

@@ -19,13 +19,13 @@ namespace hicmi {
 // consecutive cells - then ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by shuffles and the tree over the leaf sums by lane 0
 // (stacks in LDS).  The earlier one-lane-per-row version walked the tree with a private stack, i.e. in scratch memory.
 __global__ __launch_bounds__(64) void k_row_sums_np(const double* __restrict__ C, int64_t ldc, int n,
-                                                    double* __restrict__ np_sum)
+                                                    double* __restrict__ np_sum, int row_first, int row_stride)
 {
     __shared__ int leaf_off[MAX_LEAVES], leaf_len[MAX_LEAVES], leaf_dep[MAX_LEAVES];
     __shared__ double leaf_sum[MAX_LEAVES];
     __shared__ int s_nleaves, st_a[16], st_b[16], st_c[16];
     __shared__ double st_v[16];
-    const int row = blockIdx.x, lane = threadIdx.x, slot = lane >> 3, k = lane & 7;
+    const int row = row_first + blockIdx.x * row_stride, lane = threadIdx.x, slot = lane >> 3, k = lane & 7;   // one of this shard's rows
     const double* __restrict__ a = C + (int64_t)row * ldc;
     double acc = 0.0;                                   // chunk results accumulate left to right from 0.0
     for (int c0 = 0; c0 < n; c0 += 8192) {
@@ -63,9 +63,9 @@ __global__ __launch_bounds__(64) void k_row_sums_np(const double* __restrict__ C
 // Python's builtin sum(): strictly left to right, one lane per row (the chain cannot be split); 16-byte loads, eight
 // cells fetched ahead of the adds.
 __global__ __launch_bounds__(64) void k_row_sums_seq(const double* __restrict__ C, int64_t ldc, int n,
-                                                     double* __restrict__ seq_sum)
+                                                     double* __restrict__ seq_sum, int row_first, int row_stride)
 {
-    const int row = blockIdx.x * 64 + threadIdx.x;
+    const int row = row_first + (blockIdx.x * 64 + threadIdx.x) * row_stride;
     if (row >= n) return;
     const double* __restrict__ a = C + (int64_t)row * ldc;          // ldc is a multiple of 2 cells or the row is read cell-wise
     double s = 0.0;
@@ -81,10 +81,14 @@ __global__ __launch_bounds__(64) void k_row_sums_seq(const double* __restrict__ 
     seq_sum[row] = s;
 }
 
-void launch_row_sums(const double* C, int64_t ldc, int n, double* np_sum, double* seq_sum, hipStream_t s)
+// rows row_first, row_first + row_stride, ... (the whole matrix for 0, 1)
+void launch_row_sums(const double* C, int64_t ldc, int n, double* np_sum, double* seq_sum, int row_first, int row_stride,
+                     hipStream_t s)
 {
-    hipLaunchKernelGGL(k_row_sums_np, dim3(n), dim3(64), 0, s, C, ldc, n, np_sum);
-    hipLaunchKernelGGL(k_row_sums_seq, dim3((n + 63) / 64), dim3(64), 0, s, C, ldc, n, seq_sum);
+    const int mine = n > row_first ? (n - row_first + row_stride - 1) / row_stride : 0;
+    if (mine <= 0) return;
+    hipLaunchKernelGGL(k_row_sums_np, dim3(mine), dim3(64), 0, s, C, ldc, n, np_sum, row_first, row_stride);
+    hipLaunchKernelGGL(k_row_sums_seq, dim3((mine + 63) / 64), dim3(64), 0, s, C, ldc, n, seq_sum, row_first, row_stride);
 }
 
 // removeRows (S2C:100-136): dst = src[keep][:, keep]
@@ -153,10 +157,10 @@ void launch_build_w(const double* C, int64_t ldc, const double* np_sum, int n, d
 // (mode 1: hi = c, L = c - lo) is a count over a CONTIGUOUS uint16 segment of one row:
 // coalesced 16-byte loads, wave-shuffle + LDS reduction.  HBM-bound: 2 bytes per element read.
 __global__ __launch_bounds__(256) void k_cut_count(const uint16_t* __restrict__ rank, int64_t ldr, int row0, int lo,
-                                                   int mode, int cparam, int32_t* __restrict__ x_out)
+                                                   int mode, int cparam, int32_t* __restrict__ x_out, int row_step)
 {
     __shared__ int s_part[4];
-    const int i = row0 + blockIdx.x;
+    const int i = row0 + blockIdx.x * row_step;             // row_step > 1: this shard's rows only
     const int hi = mode == 0 ? i : cparam;
     const int thr = hi - lo;
     const uint16_t* __restrict__ r = rank + (int64_t)i * ldr;
@@ -179,23 +183,27 @@ __global__ __launch_bounds__(256) void k_cut_count(const uint16_t* __restrict__ 
     for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
     if ((tid & 63) == 0) s_part[tid >> 6] = cnt;
     __syncthreads();
-    if (tid == 0) x_out[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (tid == 0) x_out[blockIdx.x * row_step] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
 }
 
+// x_out[t] = count of row row0 + t, for t = 0, row_step, 2 row_step, ... < nrows (entries in between are not written)
 void launch_cut_count(const uint16_t* rank, int64_t ldr, int row0, int nrows, int lo, int mode, int cparam,
-                      int32_t* x_out, hipStream_t s)
+                      int32_t* x_out, int row_step, hipStream_t s)
 {
     if (nrows <= 0) return;
-    hipLaunchKernelGGL(k_cut_count, dim3(nrows), dim3(256), 0, s, rank, ldr, row0, lo, mode, cparam, x_out);
+    const int blocks = (nrows + row_step - 1) / row_step;
+    hipLaunchKernelGGL(k_cut_count, dim3(blocks), dim3(256), 0, s, rank, ldr, row0, lo, mode, cparam, x_out, row_step);
 }
 
 // sig flags from counts.  mode 0 (first pass, S2C:455-469): entry t >= 1 tests L = t, NaN -> 1,
 // entry 0 is forced to 0.  mode 1 (filter, S2C:631-636): every entry tests L = L_fixed, NaN -> 0.
 __global__ __launch_bounds__(256) void k_hyper_flags(const int32_t* __restrict__ x, int nrows, int mode, int L_fixed,
-                                                     int64_t M, double psig, uint8_t* __restrict__ sig)
+                                                     int64_t M, double psig, uint8_t* __restrict__ sig, int own_first,
+                                                     int own_step)
 {
     int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= nrows) return;
+    if (own_step > 1 && (t < own_first || (t - own_first) % own_step != 0)) { sig[t] = 0; return; }   // another shard's row
     if (mode == 0) {
         if (t == 0) { sig[0] = 0; return; }
         double p = hypergeom_sf_ge((int64_t)x[t], M, (int64_t)t, (int64_t)t);
@@ -206,11 +214,13 @@ __global__ __launch_bounds__(256) void k_hyper_flags(const int32_t* __restrict__
     }
 }
 
+// own_step > 1: only entries own_first, own_first + own_step, ... are tested, the others are written as 0
 void launch_hyper_flags(const int32_t* x, int nrows, int mode, int L_fixed, int64_t M, double psig, uint8_t* sig,
-                        hipStream_t s)
+                        int own_first, int own_step, hipStream_t s)
 {
     if (nrows <= 0) return;
-    hipLaunchKernelGGL(k_hyper_flags, dim3((nrows + 255) / 256), dim3(256), 0, s, x, nrows, mode, L_fixed, M, psig, sig);
+    hipLaunchKernelGGL(k_hyper_flags, dim3((nrows + 255) / 256), dim3(256), 0, s, x, nrows, mode, L_fixed, M, psig, sig,
+                       own_first, own_step);
 }
 
 // fp32 -> fp64 in place.  dst has `cells` doubles; the fp32 image sits in the upper half of the same bytes

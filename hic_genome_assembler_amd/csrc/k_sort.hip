@@ -76,7 +76,7 @@ __device__ __forceinline__ void lds_stages(uint64_t* lk, uint16_t* li, int tile,
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_rows(
     const double* __restrict__ C, int64_t ldc, const int32_t* __restrict__ order, const double* __restrict__ np_sum,
     const double* __restrict__ seq_sum, int n, int P, uint64_t* __restrict__ skeys, uint16_t* __restrict__ sidx,
-    uint16_t* __restrict__ R, int64_t ldr)
+    uint16_t* __restrict__ R, int64_t ldr, int row_first, int row_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tile = P < SORT_TILE ? P : SORT_TILE;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_rows(
     uint64_t* gk = skeys + (size_t)blockIdx.x * (size_t)P;
     uint16_t* gi = sidx + (size_t)blockIdx.x * (size_t)P;
 
-    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+    for (int row = row_first + blockIdx.x * row_stride; row < n; row += gridDim.x * row_stride) {
         const int pa = order[row];
         const double sig = np_sum[pa], rs = seq_sum[pa];
         const double* __restrict__ crow = C + (int64_t)pa * ldc;
@@ -229,7 +229,7 @@ __device__ __forceinline__ void rb_tile_stages(uint64_t (&K)[RB_E], uint32_t (&I
 __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
     const double* __restrict__ C, int64_t ldc, const int32_t* __restrict__ order, const double* __restrict__ np_sum,
     const double* __restrict__ seq_sum, int n, int P, uint64_t* __restrict__ skeys, uint16_t* __restrict__ sidx,
-    uint16_t* __restrict__ R, int64_t ldr, const int32_t* __restrict__ inv)
+    uint16_t* __restrict__ R, int64_t ldr, const int32_t* __restrict__ inv, int row_first, int row_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* xk = reinterpret_cast<uint64_t*>(smem);                                   // (RB_E / 2) x RB_T keys
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
     uint64_t K[RB_E];
     uint32_t I[RB_E];
 
-    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+    for (int row = row_first + blockIdx.x * row_stride; row < n; row += gridDim.x * row_stride) {   // this shard's rows
         const int pa = order[row];
         const double sig = np_sum[pa], rs = seq_sum[pa];
         const double* __restrict__ crow = C + (int64_t)pa * ldc;
@@ -311,7 +311,8 @@ __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
 
 // order: leaf order (row r of the result is storage row order[r]); inv: its inverse (position of a storage column)
 void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const int32_t* inv, const double* np_sum,
-                      const double* seq_sum, int n, void* scratch, uint16_t* R, int64_t ldr, hipStream_t s)
+                      const double* seq_sum, int n, void* scratch, uint16_t* R, int64_t ldr, int row_first, int row_stride,
+                      hipStream_t s)
 {
     static const bool lds_network = getenv("HICMI_SORT_LDS") != nullptr;      // A/B switch: the LDS-resident network
     if (!lds_network) {
@@ -323,7 +324,7 @@ void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const 
         const size_t lds = (size_t)(RB_E / 2) * RB_T * (sizeof(uint64_t) + sizeof(uint16_t));
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_rows_rb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_sort_rows_rb, dim3(wgs), dim3(RB_T), lds, s, C, ldc, order, np_sum, seq_sum, n, P, skeys,
-                           sidx, R, ldr, inv);
+                           sidx, R, ldr, inv, row_first, row_stride);
         return;
     }
     const int P = sort_padded_size(n);
@@ -334,16 +335,16 @@ void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const 
     size_t lds = (size_t)tile * (sizeof(uint64_t) + sizeof(uint16_t));
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_sort_rows, dim3(wgs), dim3(SORT_THREADS), lds, s, C, ldc, order, np_sum, seq_sum, n, P, skeys,
-                       sidx, R, ldr);
+                       sidx, R, ldr, row_first, row_stride);
 }
 
 // rank[row][R[row][k]] = k : scatter inside LDS (2 bytes per bin), coalesced in and out.
 __global__ __launch_bounds__(1024) void k_rank_invert(const uint16_t* __restrict__ R, uint16_t* __restrict__ rank,
-                                                      int64_t ldr, int n)
+                                                      int64_t ldr, int n, int row_first, int row_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* inv = reinterpret_cast<uint16_t*>(smem);
-    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+    for (int row = row_first + blockIdx.x * row_stride; row < n; row += gridDim.x * row_stride) {
         const uint16_t* __restrict__ r = R + (int64_t)row * ldr;
         for (int k = threadIdx.x; k < n; k += 1024) inv[r[k]] = (uint16_t)k;
         __syncthreads();
@@ -353,12 +354,12 @@ __global__ __launch_bounds__(1024) void k_rank_invert(const uint16_t* __restrict
     }
 }
 
-void launch_rank_invert(const uint16_t* R, uint16_t* rank, int64_t ldr, int n, hipStream_t s)
+void launch_rank_invert(const uint16_t* R, uint16_t* rank, int64_t ldr, int n, int row_first, int row_stride, hipStream_t s)
 {
     size_t lds = ((size_t)n * sizeof(uint16_t) + 15) & ~(size_t)15;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_invert), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int grid = n < 1024 ? n : 1024;
-    hipLaunchKernelGGL(k_rank_invert, dim3(grid), dim3(1024), lds, s, R, rank, ldr, n);
+    hipLaunchKernelGGL(k_rank_invert, dim3(grid), dim3(1024), lds, s, R, rank, ldr, n, row_first, row_stride);
 }
 
 __global__ __launch_bounds__(256) void k_similarity_row(const double* __restrict__ C, int64_t ldc,

@@ -2,9 +2,11 @@
 in the CPU tests).
 
 What shards in this path: whole maps (independent genomes) and, inside one map,
-the chromosomes of Part 2.  The UPGMA chain does not.  Work units are therefore dealt to ranks with
-no collective in the data path; the only exchanges are a barrier, a MAX-reduction of the elapsed
-time and an object gather of the (tiny) per-unit results.
+(a) the row-independent stages of Part 1 - row sums, the per-row argsort / rank matrix, the per-row
+counts of every cut and filter scan - by a cyclic row partition (hicmi_set_row_shard), with ONE
+all-gather of the owned entries per vector (``gather_owned``: N / world row sums, or N / world flags
+per scan), and (b) the chromosomes of Part 2, with one object all-gather of the ordered lists.  The
+UPGMA chain does not shard (replicated).  Besides those: a barrier and a MAX-reduction of the time.
 """
 from __future__ import annotations
 
@@ -61,4 +63,36 @@ def gather_results(local: dict) -> dict:
     out = {}
     for p in parts:
         out.update(p)
+    return out
+
+
+def gather_owned(local, first_row: int, rank: int, world: int):
+    """All-gather of a per-row vector whose entries were computed by the rank that owns the row.
+
+    ``local``: 1-D NumPy array over the rows ``first_row, first_row + 1, ...``; entry t is meaningful on this rank
+    iff ``(first_row + t) % world == rank`` (the cyclic row partition of hicmi_set_row_shard).  Every rank sends its
+    owned entries (N / world of them); the result has every entry filled in, identical on all ranks.
+    Backend "nccl" (RCCL): the pieces travel as device tensors; "gloo": as host tensors."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    local = np.ascontiguousarray(local)
+    if world <= 1 or not (dist.is_available() and dist.is_initialized()):
+        return local
+    n = len(local)
+    chunk = (n + world - 1) // world                      # owned entries per rank, padded to a common length
+    t0 = (rank - first_row) % world
+    mine = local[t0::world]
+    send = np.zeros(max(chunk, 1), dtype=local.dtype)
+    send[:len(mine)] = mine
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t_send = torch.from_numpy(send).to(dev)
+    t_recv = torch.empty(world * len(send), dtype=t_send.dtype, device=dev)
+    dist.all_gather_into_tensor(t_recv, t_send)
+    parts = t_recv.cpu().numpy().reshape(world, len(send))
+    out = np.empty_like(local)
+    for r in range(world):
+        tr = (r - first_row) % world
+        cnt = len(range(tr, n, world))
+        out[tr::world] = parts[r, :cnt]
     return out

@@ -30,6 +30,7 @@ import time
 import numpy as np
 
 from . import _lib
+from . import dist as _dist
 from . import modularity as louvain
 from . import plotContactMaps as plotModule
 from .hostio import Bin, initiateLoci, paused_gc, read_contact_matrix, read_contact_matrix_cached  # noqa: F401  (re-exported reference names)
@@ -82,6 +83,11 @@ def removeRows(matrix: DeviceMatrix, binList, zeroRows=True, biasVals=False):
     """S2C:100-136: drop rows (and columns) whose NumPy row sum is 0, then store each bin's
     left-to-right row sum.  ``biasVals`` filtering is kept for signature compatibility."""
     np_sum, seq_sum = matrix.ctx.row_sums()
+    first, world = getattr(matrix.ctx, "shard", (0, 1))
+    if world > 1:                                          # one map over several GPUs: every rank summed its own rows
+        np_sum = _dist.gather_owned(np_sum, 0, first, world)
+        seq_sum = _dist.gather_owned(seq_sum, 0, first, world)
+        matrix.ctx.set_row_sums(np_sum, seq_sum)
     dropped = np.zeros(len(binList), dtype=bool)
     if zeroRows is True:
         dropped |= np.asarray(np_sum) == 0
@@ -190,10 +196,13 @@ def find_matrix_pvalue_breakpoints(argsorted_mat: RankMatrix, start, min_size, w
     The window-shrinking retry of S2C:499-508 cannot produce a cut (its scores are < min_size while
     S2C:488 tests == min_size), so it is not repeated."""
     ctx = argsorted_mat.ctx
+    first, world = getattr(ctx, "shard", (0, 1))
     M = world_size
     loop_count = 0
     while True:
         sig = ctx.cut_scan(int(start), int(M), float(psig))
+        if world > 1:                                      # flags of this rank's rows -> all rows (one all-gather per scan)
+            sig = _dist.gather_owned(sig, int(start), first, world)
         loop_count += 1
         if (int(sig.sum()) / len(sig)) >= .9:
             morg = M
@@ -237,6 +246,7 @@ def filter_noisy_breakpoints(argsorted_mat: RankMatrix, original_inds, psig=.05)
     if len(original_inds) == 0:
         return []
     ctx = argsorted_mat.ctx
+    first, world = getattr(ctx, "shard", (0, 1))
     n = len(argsorted_mat)
     MD = int(n / 5)
     MAX_ROUNDS = 10 * len(original_inds)
@@ -257,7 +267,8 @@ def filter_noisy_breakpoints(argsorted_mat: RankMatrix, original_inds, psig=.05)
                 local = c - start
                 n_rows = min(n - start, MD + 1)            # rows beyond start+MD are forced to 0 (S2C:626-628)
                 flags = np.zeros(n - start, dtype=np.int64)
-                flags[:n_rows] = ctx.filter_scan(start, c, n_rows, M, float(psig))
+                own = ctx.filter_scan(start, c, n_rows, M, float(psig))
+                flags[:n_rows] = _dist.gather_owned(own, start, first, world) if world > 1 else own
                 sig_cuts = []
                 fc_prev = start
                 for ai_ind, ai in enumerate(altered):
@@ -423,8 +434,9 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, hicProScaffSize
                 dendrogramOrderFile, avgClusterPlot, avgClusterPlot_outlined,
                 binGroupFile, assessmentFile, chromosomeGroupFile,
                 hyperGeom, hmm, minSize, modularity, louvainRounds,
-                psig, convergenceRounds, lookAhead, resolution, device=0):
-    """S2C:1104-1174, same positional arguments (``device`` is an optional extra)."""
+                psig, convergenceRounds, lookAhead, resolution, device=0, shard=None):
+    """S2C:1104-1174, same positional arguments (``device`` and ``shard`` are optional extras; ``shard=(rank, world)``:
+    this process is one of ``world`` that work on the same map, see runResident)."""
     print("########################################")
     print("### Working on Part1 of the pipeline ###")
     t_all = time.time()
@@ -436,7 +448,7 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, hicProScaffSize
     try:
         cutIndices = runResident(adjMat, binList, hicProScaffSizeFile, dendrogramOrderFile, binGroupFile,
                                  assessmentFile, chromosomeGroupFile, minSize, modularity, psig,
-                                 louvainRounds=louvainRounds)
+                                 louvainRounds=louvainRounds, shard=shard)
         # S2C:1124 / S2C:1155-1156: the clustered distance matrix, then - groups outlined - the distance transform of
         # the un-logged similarity matrix, which is the distance matrix again up to a few roundings
         if plotModule.plots_enabled(avgClusterPlot):
@@ -453,12 +465,17 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, hicProScaffSize
 
 
 def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOrderFile, binGroupFile,
-                assessmentFile, chromosomeGroupFile, minSize, modularity, psig, louvainRounds=20):
+                assessmentFile, chromosomeGroupFile, minSize, modularity, psig, louvainRounds=20, shard=None):
     """S2C:1117-1167 on a contact map that is already resident in HBM (what bench.py times): every
     stage after the text loaders, including the small intermediate files the reference round-trips
     through.  Returns the filtered cut indices; ``binList`` is left in .bed order for the caller."""
     with paused_gc():
         t0 = time.time()
+        if shard is not None:
+            # ONE map over shard[1] ranks (SURVEY 8e): the row sums, the row sort / rank matrix and the per-row counts of
+            # the scans are computed for rows == shard[0] (mod shard[1]) only and all-gathered; UPGMA and the host control
+            # flow run on every rank (deterministic: all ranks write the same files)
+            adjMat.ctx.set_row_shard(shard[0], shard[1])
         adjMat, binList = removeRows(adjMat, binList, zeroRows=True, biasVals=False)
         adjMat.kept_bins = list(binList)                  # rows of the device matrix, in .bed order
         adjMat = convertMatrix(adjMat, binList, distance=True, similarity=False)

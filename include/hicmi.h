@@ -78,6 +78,18 @@ int hicmi_load_hicpro_matrix(const char *path, const int64_t *bin_ids, int64_t n
  * Either output may be NULL.  Results are also kept on the device for the later stages. */
 int hicmi_row_sums(hicmi_ctx *ctx, double *np_sum, double *seq_sum);
 
+/* One map over several GPUs (first bullet): the row-independent stages - row sums (S2C:112,134), the
+ * per-row argsort (S2C:1132) and the per-row counts of the cut and filter scans (S2C:455-459, 622-636) - are computed
+ * only for the rows first, first + stride, first + 2 stride, ... of this context (a CYCLIC row partition: the scans
+ * read a triangle of the rank matrix, contiguous blocks would leave the last rank with most of it).  Afterwards
+ *   hicmi_row_sums      fills only the owned entries (0 elsewhere) until hicmi_set_row_sums installs the gathered vectors,
+ *   hicmi_rank_matrix   sorts and inverts only the owned rows,
+ *   hicmi_cut_scan / hicmi_filter_scan  return counts and flags of the owned rows, 0 for the others;
+ * the caller all-gathers the owned entries across the ranks (hic_genome_assembler_amd/dist.py: RCCL through
+ * torch.distributed).  first = 0, stride = 1 (the default) is the whole matrix. */
+int hicmi_set_row_shard(hicmi_ctx *ctx, int64_t first, int64_t stride);
+int hicmi_set_row_sums(hicmi_ctx *ctx, const double *np_sum, const double *seq_sum);
+
 /* removeRows (S2C:100-136): keep only rows/columns keep[0..n_keep) (ascending); recomputes both
  * row sums on the compacted matrix.  The compacted copy is owned by the context (an adopted
  * device matrix is left untouched). */
@@ -127,6 +139,11 @@ int hicmi_leaf_order(const double *Z, int64_t n, int32_t *leaves_out);
 int hicmi_selftest_division(hicmi_ctx *ctx, uint64_t seed, int64_t samples, uint64_t *mismatches_out);
 /* Raw merges (x, y, height, size) in nn-chain merge order from the last hicmi_upgma. */
 int hicmi_get_raw_merges(hicmi_ctx *ctx, double *Zraw_out);
+/* Counters of the nn-chain kernels (scipy average, S2C:197) since the last hicmi_timing_reset, 6 doubles:
+ * [0] merges, [1] row scans, [2] columns those scans visited (the "sum over scans of the live columns" of the
+ * algorithmic-bytes definition), [3] chain steps answered by the neighbour cache instead of a scan,
+ * [4] re-runs on one workgroup after a late peer of the column-sliced kernel, [5] reserved. */
+int hicmi_nnchain_stats(hicmi_ctx *ctx, double *out6);
 
 /* ---- Part 2: ordering objective --------------------------------------------------------------
  * giveNewAdjMat (OG:296-308): select the sub-matrix of the context's contact matrix for the bins

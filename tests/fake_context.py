@@ -11,6 +11,19 @@ class OracleContext:
     def __init__(self, device=0):
         self.n = 0
         self.mat = None
+        self.shard = (0, 1)
+        self._sums = None
+
+    # ---- one map over several ranks: like libhicmi, answer only for the owned rows until the sums are installed
+    def set_row_shard(self, first, stride):
+        self.shard = (int(first), int(stride))
+
+    def set_row_sums(self, np_sum, seq_sum):
+        self._sums = (np.array(np_sum), np.array(seq_sum))
+
+    def _owned(self, first_row, count):
+        first, stride = self.shard
+        return (np.arange(first_row, first_row + count) % stride) == first
 
     def close(self):
         pass
@@ -24,13 +37,19 @@ class OracleContext:
     def set_contacts(self, mat):
         self.mat = np.ascontiguousarray(mat, dtype=np.float64)
         self.n = len(self.mat)
+        self._sums = None
 
     def row_sums(self):
-        return orc.np_row_sums(self.mat), orc.seq_row_sums(self.mat)
+        a, b = orc.np_row_sums(self.mat), orc.seq_row_sums(self.mat)
+        if self.shard[1] > 1 and self._sums is None:
+            own = self._owned(0, self.n)
+            return np.where(own, a, 0.0), np.where(own, b, 0.0)
+        return a, b
 
     def compact(self, keep):
         keep = np.asarray(keep, dtype=np.int64)
         self.set_contacts(self.mat[np.ix_(keep, keep)])
+        self._sums = (None, None)                          # libhicmi recomputes all sums on the compacted matrix
 
     def upgma(self, want_linkage=True):
         leaves, z = orc.average_cluster_leaves(orc.to_distance(self.mat))
@@ -78,6 +97,9 @@ class OracleContext:
         L = np.arange(1, self.n - start)
         p = orc.hyper_geom(x[1:], M, L, L)
         sig = np.concatenate(([0], np.where(p >= psig, 0, 1))).astype(np.uint8)
+        if self.shard[1] > 1:
+            own = self._owned(start, len(sig))
+            sig, x = np.where(own, sig, 0).astype(np.uint8), np.where(own, x, 0)
         return (sig, x.astype(np.int32)) if want_x else sig
 
     def filter_scan(self, start, c, n_rows, M, psig, want_x=False):
@@ -85,6 +107,9 @@ class OracleContext:
         x = np.count_nonzero((sub >= start) & (sub <= c), axis=1)
         p = orc.hyper_geom(x, M, c - start, c - start)
         sig = np.where(p < psig, 1, 0).astype(np.uint8)
+        if self.shard[1] > 1:
+            own = self._owned(start, len(sig))
+            sig, x = np.where(own, sig, 0).astype(np.uint8), np.where(own, x, 0)
         return (sig, x.astype(np.int32)) if want_x else sig
 
     def p2_select(self, sel):

@@ -174,3 +174,89 @@ def test_chromosome_deal_is_balanced_and_complete():
     assert two[0] == [1] or 1 in two[0]                           # the largest goes to rank 0
     load = [sum(len(chroms[i]) ** 2 for i in d) for d in two]
     assert max(load) <= 1.3 * min(load)
+
+
+# ---- one map, Part 1's row-independent stages sharded over the ranks (first bullet) ----------------------
+def _run_part1_sharded(rank, world, name, tmp):
+    import contextlib
+    import io
+    import numpy as np
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import golden_cases as gc
+    from fake_context import OracleContext
+    import hic_oracle as orc
+    from hic_genome_assembler_amd import _lib, scaffoldToChromosomes as p1
+    seen = {"scans": 0, "foreign_nonzero": 0, "owned_rows": 0}
+
+    class Spy(OracleContext):
+        def cut_scan(self, start, M, psig, want_x=False):
+            sig = OracleContext.cut_scan(self, start, M, psig, want_x)
+            rows = np.arange(start, start + len(sig))
+            seen["scans"] += 1
+            seen["foreign_nonzero"] += int(np.count_nonzero(sig[rows % world != rank]))
+            seen["owned_rows"] += int(np.count_nonzero(rows % world == rank))
+            return sig
+
+        def filter_scan(self, start, c, n_rows, M, psig, want_x=False):
+            sig = OracleContext.filter_scan(self, start, c, n_rows, M, psig, want_x)
+            rows = np.arange(start, start + len(sig))
+            seen["scans"] += 1
+            seen["foreign_nonzero"] += int(np.count_nonzero(sig[rows % world != rank]))
+            return sig
+    _lib.Context = Spy
+    _lib.hypergeom_sf = lambda x, M, n, N: float(orc.hyper_geom(x, M, n, N))
+    spec = gc.load_case(name)[0]
+    paths = gc.write_case_files(name, tmp)
+    f = lambda k: os.path.join(tmp, k)  # noqa: E731
+    with contextlib.redirect_stdout(io.StringIO()):
+        p1.runPipeline(paths["hicProBedFile"], paths["hicProBiasFile"], paths["hicProMatrixFile"],
+                       paths["hicProScaffSizeFile"], f("dendrogramOrder.txt"), f("a.png"), f("b.png"),
+                       f("binGroups.txt"), f("assessment.txt"), f("chromosomeGroups.txt"),
+                       True, False, spec["min_size"], 0.0, 20, spec["psig"], 5, .2, 100000, shard=(rank, world))
+    files = {fn: open(f(fn)).read() for fn in ("dendrogramOrder.txt", "binGroups.txt", "assessment.txt", "chromosomeGroups.txt")}
+    return files, seen
+
+
+def _part1_shard_worker(rank, world, port, tmp_root, name, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path[:0] = [ROOT]
+    from hic_genome_assembler_amd import dist
+    dist.init("gloo")
+    tmp = os.path.join(tmp_root, "p1_r%d" % rank)
+    os.makedirs(tmp)
+    files, seen = _run_part1_sharded(rank, world, name, tmp)
+    everything = dist.gather_results({rank: {"files": files, "seen": seen}})
+    if rank == 0:
+        import json
+        with open(os.path.join(out_dir, "part1_sharded.json"), "w") as fh:
+            json.dump({str(k): v for k, v in everything.items()}, fh)
+    dist.barrier()
+
+
+@pytest.mark.parametrize("name,world", [("n600", 2), ("n300_edges", 3)])
+def test_one_map_part1_rows_sharded_over_the_ranks(tmp_path, name, world):
+    """Every rank sums, sorts and scans only the rows r == rank (mod world) (here: the oracle-backed context answers
+    0 for everybody else's rows, as libhicmi does after hicmi_set_row_shard); one all-gather per vector gives every
+    rank the full flags, and all ranks write the reference's four Part 1 files."""
+    import json
+    sys.path[:0] = [os.path.join(ROOT, "tests")]
+    import golden_cases as gc
+    port = 29600 + (os.getpid() % 90) + world
+    mp.spawn(_part1_shard_worker, args=(world, port, str(tmp_path), name, str(tmp_path)), nprocs=world, join=True)
+    with open(tmp_path / "part1_sharded.json") as fh:
+        got = json.load(fh)
+    assert sorted(got) == [str(r) for r in range(world)]
+    for r in range(world):
+        for fn, text in got[str(r)]["files"].items():
+            assert text == gc.golden_text(name, fn), (r, fn)
+        seen = got[str(r)]["seen"]
+        assert seen["scans"] > 10 and seen["foreign_nonzero"] == 0 and seen["owned_rows"] > 0
+
+
+def test_gather_owned_single_process_is_identity():
+    sys.path[:0] = [ROOT]
+    import numpy as np
+    from hic_genome_assembler_amd import dist
+    a = np.arange(7, dtype=np.int32)
+    assert dist.gather_owned(a, 3, 0, 1) is not None and np.array_equal(dist.gather_owned(a, 3, 0, 1), a)

@@ -1,6 +1,8 @@
 """One map over two ranks ON THE GPU: both processes open libhicmi contexts on cuda:0 (gloo carries the
-object all-gather, as RCCL does on a multi-GPU node), Part 1 runs on each, Part 2's chromosomes are
-dealt to the ranks (orderGenome shard=) and the files rank 0 writes must be the reference's."""
+all-gathers, as RCCL does on a multi-GPU node).  Part 1's row-independent stages are sharded by rows
+(hicmi_set_row_shard: each rank sums, sorts and scans only its rows; one all-gather per vector), UPGMA
+runs on both, Part 2's chromosomes are dealt to the ranks (orderGenome shard=) and the files must be
+the reference's."""
 import json
 import os
 import sys
@@ -26,6 +28,24 @@ def _worker(rank, world, port, tmp_root, name):
     from hic_genome_assembler_amd.hostio import initiateLoci
     _lib.load()                                                   # the HIP library or nothing
     dist.init("gloo")
+    import numpy as np
+    seen = {"scans": 0, "foreign_nonzero": 0}
+    inner_cut, inner_filter = _lib.Context.cut_scan, _lib.Context.filter_scan
+
+    def spy_cut(self, start, M, psig, want_x=False):
+        sig = inner_cut(self, start, M, psig, want_x)
+        rows = np.arange(start, start + len(sig))
+        seen["scans"] += 1
+        seen["foreign_nonzero"] += int(np.count_nonzero(sig[rows % world != rank]))
+        return sig
+
+    def spy_filter(self, start, c, n_rows, M, psig, want_x=False):
+        sig = inner_filter(self, start, c, n_rows, M, psig, want_x)
+        rows = np.arange(start, start + len(sig))
+        seen["scans"] += 1
+        seen["foreign_nonzero"] += int(np.count_nonzero(sig[rows % world != rank]))
+        return sig
+    _lib.Context.cut_scan, _lib.Context.filter_scan = spy_cut, spy_filter
     tmp = os.path.join(tmp_root, "r%d" % rank)
     os.makedirs(tmp)
     spec = cases.load_case(name)[0]
@@ -35,7 +55,7 @@ def _worker(rank, world, port, tmp_root, name):
         p1.runPipeline(paths["hicProBedFile"], paths["hicProBiasFile"], paths["hicProMatrixFile"],
                        paths["hicProScaffSizeFile"], f("dendrogramOrder.txt"), f("a.png"), f("b.png"),
                        f("binGroups.txt"), f("assessment.txt"), f("chromosomeGroups.txt"),
-                       True, False, spec["min_size"], 0.0, 20, spec["psig"], 5, .2, 100000)
+                       True, False, spec["min_size"], 0.0, 20, spec["psig"], 5, .2, 100000, shard=(rank, world))
         chroms = p2.readChromsFromFile(f("chromosomeGroups.txt"))
         binDict = p2.readGroupingsToValidBins(f("chromosomeGroups.txt"))
         binList = initiateLoci(paths["hicProBedFile"], paths["hicProBiasFile"], binID_dict=binDict)
@@ -47,6 +67,10 @@ def _worker(rank, world, port, tmp_root, name):
         finally:
             adj.ctx.close()
     assert len(ordered) == len(chroms)
+    assert seen["scans"] > 10 and seen["foreign_nonzero"] == 0    # this rank only ever flagged its own rows
+    part1 = {fn: open(f(fn)).read() for fn in ("dendrogramOrder.txt", "binGroups.txt", "assessment.txt", "chromosomeGroups.txt")}
+    for fn, text in part1.items():
+        assert text == cases.golden_text(name, fn), (rank, fn)   # every rank wrote the reference's Part 1 files
     mine = p2.chromosomesOfRank(chroms, rank, world)
     deals = dist.gather_results({rank: mine})
     if rank == 0:

@@ -112,14 +112,19 @@ def test_upgma_beyond_one_streaming_pass_bit_exact(hic, orc):
     assert np.array_equal(leaves, leaves_o)
 
 
+@pytest.mark.parametrize("kernel", ["mwc", "mw"])
 @pytest.mark.parametrize("wgs", [2, 4, 8])
 @pytest.mark.parametrize("n,seed,dcap", [(130, 1, 7), (600, 2, 64), (1025, 6, 1024), (2500, 7, 1024), (4099, 8, 300)])
-def test_upgma_column_sliced_chain_bit_exact(hic, orc, monkeypatch, n, seed, dcap, wgs):
-    """k_nn_epoch_mw: the chain as 2, 4 or 8 workgroups that each stream a slice of the columns and exchange their
-    (min, index) once per scan (default from 20,000 live columns; forced here for every epoch that is wide
-    enough).  Run three times: the exchange is timing-dependent, the linkage must not be."""
+def test_upgma_column_sliced_chain_bit_exact(hic, orc, monkeypatch, n, seed, dcap, wgs, kernel):
+    """The chain as 2, 4 or 8 workgroups that each stream a slice of the columns and exchange their (min, index):
+    k_nn_epoch_mwc (neighbour cache replicated in every workgroup, the next scan fused into the update: the default
+    for the wide epochs up to 32,768 live columns) and k_nn_epoch_mw (one exchange per scan, no cache: wider epochs).
+    Forced here for every epoch that is wide enough.  Run three times: the exchange is timing-dependent, the linkage
+    must not be."""
     monkeypatch.setenv("HICMI_NNCHAIN_WGS", str(wgs))
     monkeypatch.setenv("HICMI_NNCHAIN_DCAP", str(dcap))
+    if kernel == "mw":
+        monkeypatch.setenv("HICMI_NNCHAIN_MW_OLD", "1")
     rng = np.random.default_rng(seed)
     c = rng.random((n, n)) + 0.01
     c = c + c.T
@@ -144,6 +149,109 @@ def test_upgma_column_sliced_chain_default_width_at_scale(hic, orc):
     leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, c)
     assert np.array_equal(zraw, zraw_o)
     assert np.array_equal(leaves, leaves_o)
+
+
+@pytest.mark.parametrize("n,seed,dcap", [(5, 0, 1024), (65, 4, 7), (1025, 6, 64), (2500, 7, 1024)])
+def test_upgma_without_neighbour_cache_bit_exact(hic, orc, monkeypatch, n, seed, dcap):
+    """HICMI_NNCHAIN_PLAIN=1: k_nn_epoch, the chain that scans a row at every step like SciPy itself (the A/B partner
+    of the default k_nn_epoch_nc, and what tests/test_gpu_scale.py compares the default with at 32k / 64k)."""
+    monkeypatch.setenv("HICMI_NNCHAIN_PLAIN", "1")
+    monkeypatch.setenv("HICMI_NNCHAIN_DCAP", str(dcap))
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, n)) + 0.01
+    c = c + c.T
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, c)
+    assert np.array_equal(zraw, zraw_o)
+    assert np.array_equal(leaves, leaves_o)
+    ties = rng.integers(1, 4, size=(n, n)).astype(np.float64)
+    ties = np.triu(ties, 1) + np.triu(ties, 1).T + np.eye(n)
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, ties)
+    assert np.array_equal(zraw, zraw_o)
+    assert np.array_equal(leaves, leaves_o)
+
+
+@pytest.mark.parametrize("n,seed,dcap", [(5, 0, 1024), (65, 4, 7), (333, 5, 64), (1025, 6, 1024), (2500, 7, 300)])
+def test_upgma_fused_single_workgroup_bit_exact(hic, orc, monkeypatch, n, seed, dcap):
+    """HICMI_NNCHAIN_FUSED1=1: the narrow epochs on k_nn_epoch_mwc<1> - one workgroup running the column-sliced kernel's
+    fused update + scan pass (the A/B partner of k_nn_epoch_nc)."""
+    monkeypatch.setenv("HICMI_NNCHAIN_FUSED1", "1")
+    monkeypatch.setenv("HICMI_NNCHAIN_DCAP", str(dcap))
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, n)) + 0.01
+    c = c + c.T
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, c)
+    assert np.array_equal(zraw, zraw_o)
+    assert np.array_equal(leaves, leaves_o)
+    ties = rng.integers(1, 4, size=(n, n)).astype(np.float64)
+    ties = np.triu(ties, 1) + np.triu(ties, 1).T + np.eye(n)
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, ties)
+    assert np.array_equal(zraw, zraw_o)
+    assert np.array_equal(leaves, leaves_o)
+
+
+def test_upgma_neighbour_cache_counters(hic, orc):
+    """The neighbour cache answers most chain steps: on a structured map fewer than two row scans per merge are left
+    (SciPy's loop does ~2.9), the counters add up, and quantised sparse contacts - exact ties everywhere, the case
+    where the cache must defer to a scan - still give SciPy's linkage."""
+    from hic_genome_assembler_amd import synth
+    lay = synth.make_layout(1800, seed=5)
+    c = synth.dense_contacts(lay, seed=5, sinkhorn_iters=8)
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(c)
+        ctx.timing_reset()
+        leaves, z = ctx.upgma()
+        st = ctx.nnchain_stats()
+    leaves_o, z_o = orc.average_cluster_leaves(orc.to_distance(c))
+    assert np.array_equal(z, z_o) and np.array_equal(leaves, leaves_o)
+    assert st["merges"] == len(c) - 1 and st["retries"] == 0
+    assert 0.9 * st["merges"] < st["scans"] < 2.0 * st["merges"]
+    assert st["cache_hits"] > st["merges"]
+    assert st["scan_columns"] <= st["scans"] * len(c)
+    q = np.round(c, 1)
+    q[q <= np.quantile(q, 0.4)] = 0.0
+    q = 0.5 * (q + q.T)
+    np.fill_diagonal(q, np.maximum(np.diag(q), 1.0))
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, np.ascontiguousarray(q))
+    assert np.array_equal(zraw, zraw_o) and np.array_equal(leaves, leaves_o)
+
+
+def test_upgma_late_peer_falls_back_to_one_workgroup(hic, orc, monkeypatch, capfd):
+    """A peer workgroup of the column-sliced chain that does not answer in time (test hook: the 40th exchange is
+    declared late) must not fail the map: the distances are rebuilt and the chain re-runs on one workgroup."""
+    monkeypatch.setenv("HICMI_NNCHAIN_WGS", "4")
+    monkeypatch.setenv("HICMI_NNCHAIN_TEST_LATE", "40")
+    rng = np.random.default_rng(12)
+    n = 700
+    c = rng.random((n, n)) + 0.01
+    c = c + c.T
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(c)
+        ctx.timing_reset()
+        leaves, z = ctx.upgma()
+        zraw = ctx.raw_merges()
+        assert ctx.nnchain_stats()["retries"] == 1
+    dist = orc.to_distance(c)
+    assert np.array_equal(zraw, orc.nn_chain_raw(dist))
+    assert np.array_equal(leaves, orc.average_cluster_leaves(dist)[0])
+    assert "answered late" in capfd.readouterr().err
+
+
+def test_upgma_replica_divergence_is_an_error(hic, monkeypatch):
+    """Every replica of the column-sliced chain records every merge; k_nn_check_replicas compares the records after
+    each epoch.  Test hook: replica 1 falsifies the height of merge 123 - the call must fail, not return a tree."""
+    monkeypatch.setenv("HICMI_NNCHAIN_WGS", "4")
+    monkeypatch.setenv("HICMI_NNCHAIN_TEST_DIVERGE", "123")
+    rng = np.random.default_rng(13)
+    n = 600
+    c = rng.random((n, n)) + 0.01
+    c = c + c.T
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(c)
+        with pytest.raises(hic.HicmiError, match="replicas"):
+            ctx.upgma()
+        monkeypatch.delenv("HICMI_NNCHAIN_TEST_DIVERGE")
+        leaves, _z = ctx.upgma()                       # the context is usable afterwards
+        assert sorted(leaves.tolist()) == list(range(n))
 
 
 def test_upgma_widths_agree_at_32k(hic, monkeypatch):
