@@ -569,7 +569,7 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
     // nothing); the merge term is 3 * 8 * sum_{k=0}^{n-2} (n - k).
     const bool prof_on = getenv("HICMI_NNCHAIN_PROFILE") != nullptr;
     const char* cap = getenv("HICMI_NNCHAIN_DCAP");               // merges between two column flushes (tests shrink it)
-    struct { int state[16]; unsigned long long prof[8]; } nn;      // the head of the workspace
+    struct { int state[16]; unsigned long long prof[8]; unsigned char mail[640]; unsigned long long detail[32]; } nn;   // the head of the workspace
     for (int attempt = 0; attempt < 2; attempt++) {
         {
             Timed t(c, F_NNCHAIN, 0.0);
@@ -603,6 +603,11 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         fprintf(stderr, "[hicmi] nnchain phases (ms @100MHz): bookkeeping %.2f scan %.2f pick %.2f merge %.2f update %.2f; "
                         "%llu scans (%.2f per merge), %llu cached steps\n",
                 pr[0] / 1e5, pr[1] / 1e5, pr[2] / 1e5, pr[3] / 1e5, pr[4] / 1e5, pr[6], (double)pr[6] / (double)(n - 1), pr[7]);
+        const unsigned long long* dq = nn.detail;
+        if (dq[0] | dq[2] | dq[3])
+            fprintf(stderr, "[hicmi] fused pass detail (ms): issue gathers %.2f, LDS pass %.2f, loads arrive %.2f, compute+stores %.2f, "
+                            "gathered+reductions %.2f, stores acked %.2f, barrier %.2f\n",
+                    dq[0] / 1e5, dq[1] / 1e5, dq[2] / 1e5, dq[3] / 1e5, dq[4] / 1e5, dq[5] / 1e5, dq[6] / 1e5);
     }
     if (nn.state[5] == 2)
         return fail(HICMI_ESTATE, "nn-chain: a peer workgroup of the column-sliced kernel answered late, and so did the retry");

@@ -148,4 +148,59 @@ HICMI_HD double hypergeom_sf_ge(int64_t x, int64_t M, int64_t n, int64_t N)
     return sf < 0.0 ? 0.0 : sf;
 }
 
+// The only thing the reference does with hyper_geom is compare it with psig (S2C:466-469, 633-636, 669).
+// hypergeom_decide returns 1 if hyper_geom(x, M, n, N) < psig, 0 if >= psig, -1 if it is NaN - the same decision as
+// comparing hypergeom_sf_ge's value, but the tail sum stops as soon as the comparison is settled:
+//   * the partial sums are monotone, so a partial sum beyond the threshold settles it exactly;
+//   * once the term ratio is <= 1/2 the rest of the tail is <= the current term, so when even that cannot reach the
+//     threshold (with a 1e-9 relative margin) it is settled the other way.  Inside the margin the loop just goes on
+//     to the full sum, i.e. to hypergeom_sf_ge's own value.
+// A row well inside a cluster (x far above the mode) needs a few terms instead of ~50, a row at the mode (p ~ 0.5)
+// a handful instead of hundreds.
+HICMI_HD int hypergeom_decide(int64_t x, int64_t M, int64_t n, int64_t N, double psig)
+{
+    if (!(M > 0 && n >= 0 && N >= 0 && n <= M && N <= M)) return -1;
+    int64_t lo = N - (M - n); if (lo < 0) lo = 0;
+    int64_t hi = n < N ? n : N;
+    if (x <= lo) return 1.0 < psig ? 1 : 0;
+    if (x > hi) return 0.0 < psig ? 1 : 0;
+    const double r = (double)n, b = (double)(M - n), d = (double)N;
+    const double below = psig * (1.0 - 1e-9), above = psig * (1.0 + 1e-9);
+    int64_t mode = (int64_t)floor(((double)(n + 1) * (double)(N + 1)) / (double)(M + 2));
+    if (x > mode) {
+        double term = dhyper((double)x, r, b, d);
+        double sum = term;
+        if (!(sum < psig)) return sum != sum ? -1 : 0;
+        for (int64_t k = x; k < hi; k++) {
+            double num = (double)(n - k) * (double)(N - k);
+            double den = (double)(k + 1) * (double)(M - n - N + k + 1);
+            const double ratio = num / den;
+            term *= ratio;
+            double s1 = sum + term;
+            if (s1 == sum) break;
+            sum = s1;
+            if (!(sum < psig)) return 0;                          // only grows from here
+            if (ratio <= 0.5 && sum + term < below) return 1;     // the rest of the tail is <= term
+        }
+        return (sum > 1.0 ? 1.0 : sum) < psig ? 1 : 0;
+    }
+    double term = dhyper((double)(x - 1), r, b, d);
+    double sum = term;
+    if (1.0 - sum < psig) return 1;                               // sf = 1 - sum only shrinks from here
+    for (int64_t k = x - 1; k > lo; k--) {
+        double num = (double)k * (double)(M - n - N + k);
+        double den = (double)(n - k + 1) * (double)(N - k + 1);
+        const double ratio = num / den;
+        term *= ratio;
+        double s1 = sum + term;
+        if (s1 == sum) break;
+        sum = s1;
+        if (1.0 - sum < psig) return 1;
+        if (ratio <= 0.5 && 1.0 - (sum + term) > above) return 0;
+    }
+    double sf = 1.0 - sum;
+    if (sf < 0.0) sf = 0.0;
+    return sf < psig ? 1 : 0;
+}
+
 }  // namespace hicmi

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void k_nn_init(NNWorkspace w, int n)
     for (int i = gid; i < n; i += stride) { w.size[i] = 1; w.gtime[i] = -1; w.orig[i] = i; }
     if (gid < 16) w.state[gid] = 0;
     if (gid < 8) w.prof[gid] = 0ull;
+    if (gid < 32) reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(w.state) + 768)[gid] = 0ull;   // profile detail
 }
 
 // PROFILE adds wall-clock stamps (100 MHz) around the phases, accumulated in w.prof[0..4] =
@@ -1140,7 +1141,7 @@ __device__ __forceinline__ int mwc_event(u32x4 p) { return (int)((p.w >> 18) & 1
 
 static constexpr int NN_MWC_MAX = 32768;                 // sizes + cache of every column in the LDS of every replica
 
-template <int NWG>
+template <int NWG, bool PROF>
 __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict__ W, int64_t ld, int n,
                                                              int* __restrict__ chain_all, double* __restrict__ zraw,
                                                              NNWorkspace w, int dcap, int total_steps)
@@ -1190,12 +1191,15 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
     int D = 0;
     uint32_t xbit = 0u;
     unsigned int xseq = 0u;                                  // exchanges so far (uniform)
-    unsigned long long tp[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
-    const bool prof = w.state[8] != 0 && wg == 0 && tid == 0;
+    __shared__ unsigned long long s_tp[16];                  // profile: [0..4] phases, [8..14] detail of the fused pass (lane 0 only)
+    unsigned long long t0 = 0;
+    if (tid < 16) s_tp[tid] = 0;
+    const bool prof = PROF && wg == 0 && tid == 0;       // the time stamps cost ~26 registers: a separate instantiation
     int lowmark = len;                                       // lane 0: chain entries below this are still the earlier epochs'
     const int step0 = step;
     const int inject_late = w.state[10], inject_wrong = w.state[11];      // test hooks (0 = off)
-    unsigned long long c_cols = 0, c_scans = 0, c_hits = 0;
+    __shared__ unsigned long long s_cnt[3];                  // lane 0: columns visited by scans, scans, cache hits
+    if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; }
     if (tid == 0 && wg == 0) w.state[9] = step0;
     int guard = 0, stop_code = 0;                            // lane 0
     bool stopped = false;                                    // uniform
@@ -1221,14 +1225,14 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
                         chain[len] = (int)idx; ring[len & 255] = (int)idx;
                         if (len - 255 > ring_lo) ring_lo = len - 255;
                         second = top; top = (int)idx; len++;
-                        c_hits++;
+                        s_cnt[2]++;
                     }
                 }
                 s_act = act; s_x = top; s_prev = (len > 1) ? second : -1; s_tx = -1;
                 if (act == 1) {
                     xbit = smask[top >> 5] & (1u << (top & 31));
                     smask[top >> 5] &= ~xbit;
-                    c_scans++; c_cols += (unsigned long long)(total_steps + 1 - step);
+                    s_cnt[1]++; s_cnt[0] += (unsigned long long)(total_steps + 1 - step);
                 }
             }
             __syncthreads();
@@ -1237,7 +1241,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
             const int x = s_x, prev = s_prev;
             if (tid < D && dslot[tid] == x) s_tx = dtime[tid];
             __syncthreads();
-            if (prof) { t1 = wall_clock64(); tp[0] += t1 - t0; t0 = t1; }
+            if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[0] += t1 - t0; t0 = t1; }
             const int tx = s_tx;
             const double* __restrict__ rowx = W + (int64_t)x * ld;
             // every load is ISSUED before anything waits: the gathered ones (d(x, prev), the dirty partners' values from
@@ -1290,7 +1294,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
             best = argmint_wave(best);
             if (lane == 0) { s_v[wave] = best.v; s_i[wave] = best.i; s_t[wave] = best.t; }
             __syncthreads();
-            if (prof) { t1 = wall_clock64(); tp[1] += t1 - t0; t0 = t1; }
+            if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[1] += t1 - t0; t0 = t1; }
             xseq++;
             if (wave == 0) {
                 ArgMinT m = {lane < 16 ? s_v[lane] : __builtin_inf(), lane < 16 ? s_i[lane] : 0x7fffffff, lane < 16 ? s_t[lane] : 0};
@@ -1332,7 +1336,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
                 }
             }
             __syncthreads();
-            if (prof) { t1 = wall_clock64(); tp[2] += t1 - t0; t0 = t1; }
+            if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[2] += t1 - t0; t0 = t1; }
             if (s_stop) { stopped = true; break; }
         }
         if (stopped || s_act == 3) break;
@@ -1358,7 +1362,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
                 if (ia == NN_NOIDX || (int)ia == xx || (int)ia == yy) a = top;
             }
             s_a = a; s_prev = (a >= 0 && len > 1) ? second : -1;
-            if (a >= 0) { c_scans++; c_cols += (unsigned long long)(total_steps - step); }
+            if (a >= 0) { s_cnt[1]++; s_cnt[0] += (unsigned long long)(total_steps - step); }
         }
         __syncthreads();
         const int mx = s_mx, my = s_my, a = s_a, aprev = s_prev;
@@ -1368,7 +1372,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
             if (dslot[tid] == a) s_ta = dtime[tid];
         }
         __syncthreads();
-        if (prof) { t1 = wall_clock64(); tp[3] += t1 - t0; t0 = t1; }
+        if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[3] += t1 - t0; t0 = t1; }
         {
             const int tmx = s_tx, tmy = s_ty, ta = s_ta;
             const double fx = (double)s_nx, fy = (double)s_ny, fs = (double)(s_nx + s_ny);
@@ -1408,20 +1412,17 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
             ArgMinT acand = {__builtin_inf(), 0x7fffffff, 0};   // ... and its gathered candidates (dirty partners, the new cluster)
             int ev = 0;                                         // a cached minimum of this slice was reached or undercut
             bool first = true;
-            for (int j0 = c0 + tid * 2; j0 < c1 || first; j0 += 4 * NN_THREADS) {
+            if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[8] += t1 - t0; t0 = t1; }
+            // one 16-byte pair per lane and trip (x, y, a and the cached distances: four loads in flight); two pairs at once
+            // would not fit the 128 registers a 1024-lane workgroup leaves a lane
+            for (int j0 = c0 + tid * 2; j0 < c1 || first; j0 += 2 * NN_THREADS) {
                 const bool any = j0 < c1;
-                const int j1 = j0 + 2 * NN_THREADS;
-                const bool two = any && j1 < c1;
-                const int ja = any ? j0 : 0, jb = two ? j1 : ja;       // lanes without a pair re-read column 0 (always in bounds)
-                u32x4 ra0, rb0, rc0, rn0, ra1, rb1, rc1, rn1;
-                NN_LD16_SC1(ra0, rx + ja);
-                NN_LD16_SC1(rb0, ry + ja);
-                NN_LD16_SC1(rc0, ra + ja);
-                NN_LD16(rn0, w.nnval + ja);
-                NN_LD16_SC1(ra1, rx + jb);
-                NN_LD16_SC1(rb1, ry + jb);
-                NN_LD16_SC1(rc1, ra + jb);
-                NN_LD16(rn1, w.nnval + jb);
+                const int j = any ? j0 : 0;                      // lanes without a pair re-read column 0 (always in bounds)
+                u32x4 qa, qb, qc, qn;
+                NN_LD16_SC1(qa, rx + j);
+                NN_LD16_SC1(qb, ry + j);
+                NN_LD16_SC1(qc, ra + j);
+                NN_LD16(qn, w.nnval + j);
                 if (first) {
                     // while the loads are in flight: every replica drops "my neighbour is x or y" for the rows outside its
                     // slice (LDS only; the own slice is handled with the streamed / gathered values below)
@@ -1432,54 +1433,53 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
                         if (i0 == (uint32_t)mx || i0 == (uint32_t)my) nnidx[i] = (uint16_t)NN_NOIDX;
                         if (i1 == (uint32_t)mx || i1 == (uint32_t)my) nnidx[i + 1] = (uint16_t)NN_NOIDX;
                     }
+                    if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[9] += t1 - t0; t0 = t1; }
                 }
-                NN_DRAIN8(ra0, rb0, rc0, rn0, ra1, rb1, rc1, rn1);
+                NN_DRAIN4(qa, qb, qc, qn);
+                if (prof && first) { const unsigned long long t1 = wall_clock64(); s_tp[10] += t1 - t0; t0 = t1; }
                 first = false;
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    if ((h == 0 && !any) || (h == 1 && !two)) continue;
-                    const int j = h ? j1 : j0;
-                    const double2 xa = mw_pair(h ? ra1 : ra0);
-                    double2 b = mw_pair(h ? rb1 : rb0);
-                    const double2 va = mw_pair(h ? rc1 : rc0);
-                    const double2 nv = mw_pair(h ? rn1 : rn0);
-                    const uint32_t bits = smask[j >> 5] >> (j & 31);
-                    const uint32_t ip = *reinterpret_cast<const uint32_t*>(nnidx + j);
-                    const bool w0 = (bits & 1u) && j != my, w1 = (bits & 2u) && j + 1 != my;
-                    if (w0) {
-                        b.x = div_by_small_int(fx * xa.x + fy * b.x, fs, rcp);
-                        if (b.x <= rbest.v) { if (b.x < rbest.v) { rbest.v = b.x; rbest.i = j; rbest.t = 0; } else rbest.t = 1; }
-                        const uint32_t id = ip & 0xffffu;
-                        if (id == (uint32_t)mx || id == (uint32_t)my) nnidx[j] = (uint16_t)NN_NOIDX;
-                        else if (id != NN_NOIDX && b.x <= nv.x) ev = 1;
-                        if (a >= 0) {
-                            if (j == a) acand = argmint_join(acand, b.x, my, 0);          // d(a, y'), computed a moment ago
-                            else if (va.x <= abest.v) { if (va.x < abest.v) { abest.v = va.x; abest.i = j; abest.t = 0; } else abest.t = 1; }
-                        }
+                if (!any) continue;
+                const double2 xa = mw_pair(qa);
+                double2 b = mw_pair(qb);
+                const double2 va = mw_pair(qc);
+                const double2 nv = mw_pair(qn);
+                const uint32_t bits = smask[j >> 5] >> (j & 31);
+                const uint32_t ip = *reinterpret_cast<const uint32_t*>(nnidx + j);
+                const bool w0 = (bits & 1u) && j != my, w1 = (bits & 2u) && j + 1 != my;
+                if (w0) {
+                    b.x = div_by_small_int(fx * xa.x + fy * b.x, fs, rcp);
+                    if (b.x <= rbest.v) { if (b.x < rbest.v) { rbest.v = b.x; rbest.i = j; rbest.t = 0; } else rbest.t = 1; }
+                    const uint32_t id = ip & 0xffffu;
+                    if (id == (uint32_t)mx || id == (uint32_t)my) nnidx[j] = (uint16_t)NN_NOIDX;
+                    else if (id != NN_NOIDX && b.x <= nv.x) ev = 1;
+                    if (a >= 0) {
+                        if (j == a) acand = argmint_join(acand, b.x, my, 0);          // d(a, y'), computed a moment ago
+                        else if (va.x <= abest.v) { if (va.x < abest.v) { abest.v = va.x; abest.i = j; abest.t = 0; } else abest.t = 1; }
                     }
-                    if (w1) {
-                        b.y = div_by_small_int(fx * xa.y + fy * b.y, fs, rcp);
-                        if (b.y <= rbest.v) { if (b.y < rbest.v) { rbest.v = b.y; rbest.i = j + 1; rbest.t = 0; } else rbest.t = 1; }
-                        const uint32_t id = ip >> 16;
-                        if (id == (uint32_t)mx || id == (uint32_t)my) nnidx[j + 1] = (uint16_t)NN_NOIDX;
-                        else if (id != NN_NOIDX && b.y <= nv.y) ev = 1;
-                        if (a >= 0) {
-                            if (j + 1 == a) acand = argmint_join(acand, b.y, my, 0);
-                            else if (va.y <= abest.v) { if (va.y < abest.v) { abest.v = va.y; abest.i = j + 1; abest.t = 0; } else abest.t = 1; }
-                        }
-                    }
-                    // a pair store must not carry the OLD value of a dirty column (its own 8-byte store, below, is not ordered
-                    // against this one): elements that were not recomputed are left alone
-                    if (w0 && w1) {
-                        u32x4 pk;
-                        pk.x = (unsigned int)__double2loint(b.x); pk.y = (unsigned int)__double2hiint(b.x);
-                        pk.z = (unsigned int)__double2loint(b.y); pk.w = (unsigned int)__double2hiint(b.y);
-                        st16_sc1(ry + j, pk);
-                    }
-                    else if (w0) st8_sc1(ry + j, b.x);
-                    else if (w1) st8_sc1(ry + j + 1, b.y);
                 }
+                if (w1) {
+                    b.y = div_by_small_int(fx * xa.y + fy * b.y, fs, rcp);
+                    if (b.y <= rbest.v) { if (b.y < rbest.v) { rbest.v = b.y; rbest.i = j + 1; rbest.t = 0; } else rbest.t = 1; }
+                    const uint32_t id = ip >> 16;
+                    if (id == (uint32_t)mx || id == (uint32_t)my) nnidx[j + 1] = (uint16_t)NN_NOIDX;
+                    else if (id != NN_NOIDX && b.y <= nv.y) ev = 1;
+                    if (a >= 0) {
+                        if (j + 1 == a) acand = argmint_join(acand, b.y, my, 0);
+                        else if (va.y <= abest.v) { if (va.y < abest.v) { abest.v = va.y; abest.i = j + 1; abest.t = 0; } else abest.t = 1; }
+                    }
+                }
+                // a pair store must not carry the OLD value of a dirty column (its own 8-byte store, below, is not ordered
+                // against this one): elements that were not recomputed are left alone
+                if (w0 && w1) {
+                    u32x4 pk;
+                    pk.x = (unsigned int)__double2loint(b.x); pk.y = (unsigned int)__double2hiint(b.x);
+                    pk.z = (unsigned int)__double2loint(b.y); pk.w = (unsigned int)__double2hiint(b.y);
+                    st16_sc1(ry + j, pk);
+                }
+                else if (w0) st8_sc1(ry + j, b.x);
+                else if (w1) st8_sc1(ry + j + 1, b.y);
             }
+            if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[11] += t1 - t0; t0 = t1; }
             // ---- the gathered values: dirty partners of the update, candidates of row a's scan
             NN_DRAIN6(r_h, r_dp, r_dxi, r_dyi, r_nvd, r_av);
             if (want_dp) s_dprev = nn_f64(r_dp);
@@ -1502,6 +1502,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
             rbest = argmint_wave(rbest);
             abest = argmint_wave(abest);
             if (lane == 0) { s_v[wave] = rbest.v; s_i[wave] = rbest.i; s_t[wave] = rbest.t; s_v[16 + wave] = abest.v; s_i[16 + wave] = abest.i; s_t[16 + wave] = abest.t; }
+            if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[12] += t1 - t0; t0 = t1; }
             if (tid == NN_THREADS - 1) {
                 const double height = nn_f64(r_h);
                 if (wg == 0) {
@@ -1515,8 +1516,9 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
             // the stores above are inline assembly the compiler's wait-count pass does not see: every storing wave drains
             // them before the barrier behind which the exchange signals
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[13] += t1 - t0; t0 = t1; }
             __syncthreads();
-            if (prof) { t1 = wall_clock64(); tp[4] += t1 - t0; t0 = t1; }
+            if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[14] += t1 - t0; t0 = t1; }
             // ---- one exchange: the merged row's minimum (+ event flag) and row a's minimum
             xseq++;
             if (wave == 0) {
@@ -1595,7 +1597,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
         }
         __syncthreads();
         if (s_stop) break;
-        if (prof) { t1 = wall_clock64(); tp[2] += t1 - t0; }
+        if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[2] += t1 - t0; }
     }
     __syncthreads();
     if (wg != 0) return;
@@ -1611,8 +1613,16 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
     if (tid == 0) {
         w.state[0] = step; w.state[1] = len; w.state[2] = top; w.state[3] = second; w.state[4] = first_ptr;
         w.state[5] = stop_code; w.state[6] = D;
-        w.prof[5] += c_cols; w.prof[6] += c_scans; w.prof[7] += c_hits;
-        if (prof) for (int q = 0; q < 5; q++) w.prof[q] += tp[q];
+        w.prof[5] += s_cnt[0]; w.prof[6] += s_cnt[1]; w.prof[7] += s_cnt[2];
+        if (prof) {
+            for (int q = 0; q < 4; q++) w.prof[q] += s_tp[q];
+            // detail of the fused pass (profile builds only): issue gathers / LDS pass / loads arrive / compute + stores /
+            // gathered values + reductions / stores acknowledged / barrier - and the "update" phase is their sum
+            unsigned long long* p2 = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(w.state) + 768);
+            unsigned long long upd = 0;
+            for (int q = 0; q < 7; q++) { p2[q] += s_tp[8 + q]; upd += s_tp[8 + q]; }
+            w.prof[4] += upd;
+        }
     }
 }
 
@@ -1726,6 +1736,32 @@ __global__ __launch_bounds__(256) void k_nn_translate(double* __restrict__ zraw,
     zraw[4 * (int64_t)s + 1] = (double)w.orig[(int)zraw[4 * (int64_t)s + 1]];
 }
 
+template <int NWG>
+static void launch_mwc_n(bool profile, size_t lds, hipStream_t s, double* cur, int64_t ldw, int n_cur, int* chain, double* zraw,
+                         NNWorkspace w, int dcap, int total_steps)
+{
+    if (profile) hipLaunchKernelGGL((k_nn_epoch_mwc<NWG, true>), dim3(NWG), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+    else hipLaunchKernelGGL((k_nn_epoch_mwc<NWG, false>), dim3(NWG), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+}
+
+static void launch_mwc(int wgs, bool profile, size_t lds, hipStream_t s, double* cur, int64_t ldw, int n_cur, int* chain,
+                       double* zraw, NNWorkspace w, int dcap, int total_steps)
+{
+    if (wgs == 1) launch_mwc_n<1>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+    else if (wgs == 2) launch_mwc_n<2>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+    else if (wgs == 4) launch_mwc_n<4>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+    else launch_mwc_n<8>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+}
+
+static void mwc_set_lds(int bytes)
+{
+    const void* fns[] = {reinterpret_cast<const void*>(k_nn_epoch_mwc<1, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<1, true>),
+                         reinterpret_cast<const void*>(k_nn_epoch_mwc<2, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<2, true>),
+                         reinterpret_cast<const void*>(k_nn_epoch_mwc<4, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<4, true>),
+                         reinterpret_cast<const void*>(k_nn_epoch_mwc<8, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<8, true>)};
+    for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 // W and W2: two n x ldw buffers (W holds the distances on entry; both are scratch afterwards).
 // Returns the number of epoch launches.  force_single: never the column-sliced kernel (the retry after a late peer).
 int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double* zraw, void* workspace, bool profile,
@@ -1741,7 +1777,9 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     const int wgs_env = wgs_text ? atoi(wgs_text) : 0;
     const int wgs = wgs_text ? (wgs_env >= 8 ? 8 : (wgs_env >= 4 ? 4 : (wgs_env >= 2 ? 2 : 1))) : 8;
     const char* from_text = getenv("HICMI_NNCHAIN_MW_FROM");
-    const int mw_from = wgs_text ? 64 * wgs : (from_text ? atoi(from_text) : 20000);   // live columns from which an epoch runs sliced
+    // live columns from which an epoch runs sliced: with the cache and the fused scan a merge costs ~1.3 exchanges instead
+    // of ~2.9, so eight slices pay from ~6,000 columns on (16k map: nn-chain 200 -> 153 ms; 4,000 and 8,000 measure the same)
+    const int mw_from = wgs_text ? 64 * wgs : (from_text ? atoi(from_text) : 6000);
     const bool plain = getenv("HICMI_NNCHAIN_PLAIN") != nullptr;
     const bool fused1 = getenv("HICMI_NNCHAIN_FUSED1") != nullptr;       // narrow epochs on k_nn_epoch_mwc<1> instead of k_nn_epoch_nc
     const bool mw_old = getenv("HICMI_NNCHAIN_MW_OLD") != nullptr;       // k_nn_epoch_mw also where k_nn_epoch_mwc would fit (A/B, tests)
@@ -1773,10 +1811,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_nc<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nc);
         const int mc = n < NN_MWC_MAX ? n : NN_MWC_MAX, mcw4 = (((mc + 31) / 32) + 3) & ~3;
         size_t lds_mc = align16((size_t)mcw4 * 12 + (size_t)((mc + 7) & ~7) * 4);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mwc<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mc);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mwc<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mc);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mwc<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mc);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mwc<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mc);
+        mwc_set_lds((int)lds_mc);
     }
     while (done < total_steps) {
         const int nwords = (n_cur + 31) / 32, nw4 = (nwords + 3) & ~3;
@@ -1788,9 +1823,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
             cache_valid = true;
             const size_t lds_c = align16((size_t)nw4 * 12 + (size_t)((n_cur + 7) & ~7) * 4);
             hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 640, s);      // mailboxes
-            if (wgs == 2) hipLaunchKernelGGL(k_nn_epoch_mwc<2>, dim3(2), dim3(NN_THREADS), lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
-            else if (wgs == 4) hipLaunchKernelGGL(k_nn_epoch_mwc<4>, dim3(4), dim3(NN_THREADS), lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
-            else hipLaunchKernelGGL(k_nn_epoch_mwc<8>, dim3(8), dim3(NN_THREADS), lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+            launch_mwc(wgs, profile, lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
             hipLaunchKernelGGL(k_nn_check_replicas, dim3((NN_DMAX + 255) / 256), dim3(256), 0, s, w, wgs);
         }
         else if (sliced) {
@@ -1807,7 +1840,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
             cache_valid = true;
             const size_t lds_c = align16((size_t)nw4 * 12 + (size_t)((n_cur + 7) & ~7) * 4);
             hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 640, s);
-            hipLaunchKernelGGL(k_nn_epoch_mwc<1>, dim3(1), dim3(NN_THREADS), lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+            launch_mwc(1, profile, lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
         }
         else if (!plain && n_cur <= NN_NC_MAX) {
             if (!cache_valid) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);

@@ -206,11 +206,11 @@ __global__ __launch_bounds__(256) void k_hyper_flags(const int32_t* __restrict__
     if (own_step > 1 && (t < own_first || (t - own_first) % own_step != 0)) { sig[t] = 0; return; }   // another shard's row
     if (mode == 0) {
         if (t == 0) { sig[0] = 0; return; }
-        double p = hypergeom_sf_ge((int64_t)x[t], M, (int64_t)t, (int64_t)t);
-        sig[t] = (p >= psig) ? 0 : 1;
+        const int dec = hypergeom_decide((int64_t)x[t], M, (int64_t)t, (int64_t)t, psig);
+        sig[t] = dec == 0 ? 0 : 1;                              // `pval >= psig` -> 0, NaN -> 1 (S2C:466-469)
     } else {
-        double p = hypergeom_sf_ge((int64_t)x[t], M, (int64_t)L_fixed, (int64_t)L_fixed);
-        sig[t] = (p < psig) ? 1 : 0;
+        const int dec = hypergeom_decide((int64_t)x[t], M, (int64_t)L_fixed, (int64_t)L_fixed, psig);
+        sig[t] = dec == 1 ? 1 : 0;                              // `pval < psig` -> 1, NaN -> 0 (S2C:633-636)
     }
 }
 

@@ -313,15 +313,19 @@ extern "C" int hicmi_scan_valid_pairs(const char* path, const char* names_blob, 
                 col[nc++] = tab + 1;
                 q = tab + 1;
             }
-            if (nc < 6) { bad[(size_t)t] = (int64_t)(p - data); return; }   // cols[4] / cols[5] missing: IndexError in the reference
+            // the reference indexes cols[1] and cols[4] on every line (orientSmallScaffolds.py:168) and cols[2], cols[5]
+            // only for a registered pair (:170): a 5-column line that names no such pair is accepted there, so it is here
+            if (nc < 5) { bad[(size_t)t] = (int64_t)(p - data); return; }   // cols[4] missing: IndexError in the reference
+            const char* c4_end = nc >= 6 ? col[5] - 1 : le;
             const char* c5_end = nc >= 7 ? col[6] - 1 : le;
             lines[(size_t)t]++;
             auto a = name_id.find(std::string_view(col[1], (size_t)(col[2] - 1 - col[1])));
             if (a != name_id.end()) {
-                auto b = name_id.find(std::string_view(col[4], (size_t)(col[5] - 1 - col[4])));
+                auto b = name_id.find(std::string_view(col[4], (size_t)(c4_end - col[4])));
                 if (b != name_id.end()) {
                     auto hit = pair_id.find(((uint64_t)(uint32_t)a->second << 32) | (uint32_t)b->second);
                     if (hit != pair_id.end()) {
+                        if (nc < 6) { bad[(size_t)t] = (int64_t)(p - data); return; }   // cols[5] missing on a hit: IndexError there too
                         int64_t p1 = 0, p2 = 0;
                         if (!parse_pos(col[2], col[3] - 1, p1) || !parse_pos(col[5], c5_end, p2)) { bad[(size_t)t] = (int64_t)(p - data); return; }
                         out.push_back({hit->second, p1, p2});

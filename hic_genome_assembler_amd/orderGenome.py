@@ -811,14 +811,22 @@ def getChromosomeOutlineCoords(orderedChromosomes):
 
 def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, chromosomeGroupFile, chromosomeOrderFile,
                 savePlotsDirectory, chromosomePlotSuffix, fullGenomePlot, fullGenomePlotTitle, plotOrderFile,
-                nScaffolds, scanScaffolds, resolution, device=0):
-    """OG:679-712, same positional arguments (``device`` is an optional extra)."""
+                nScaffolds, scanScaffolds, resolution, device=0, resident=None):
+    """OG:679-712, same positional arguments (``device`` and ``resident`` are optional extras).
+
+    ``resident=(DeviceMatrix, bins of its rows)`` from Part 1's ``runPipeline(..., keep_resident=True)``: the contact
+    matrix already in HBM is used instead of parsing the HiC-Pro text again.  The reference re-loads the matrix
+    restricted to the grouped bins (OG:688-690); here the grouped bins are selected by ID from the full resident
+    matrix (raw contacts, .bed order) - the same cells, and bins outside every group are never touched."""
     print("########################################")
     print("### Working on Part2 of the pipeline ###")
     t0 = time.time()
-    binDict = readGroupingsToValidBins(chromosomeGroupFile)
-    binList = initiateLoci(hicProBedFile, hicProBiasFile, binID_dict=binDict)
-    adjMat = buildAdjacencyMatrix(hicProMatrixFile, binList, device=device)
+    if resident is not None:
+        adjMat, binList = GenomeMatrix(resident[0].ctx), resident[1]
+    else:
+        binDict = readGroupingsToValidBins(chromosomeGroupFile)
+        binList = initiateLoci(hicProBedFile, hicProBiasFile, binID_dict=binDict)
+        adjMat = buildAdjacencyMatrix(hicProMatrixFile, binList, device=device)
     try:
         orderedChromosomes = runResident(adjMat, binList, chromosomeGroupFile, chromosomeOrderFile, plotOrderFile,
                                          nScaffolds, scanScaffolds, resolution, savePlotDir=savePlotsDirectory,

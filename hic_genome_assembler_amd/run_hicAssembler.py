@@ -19,6 +19,7 @@ with the reference contain one and crash its parser with IndexError) is skipped 
 from __future__ import annotations
 
 import argparse
+import os
 import sys
 import time
 
@@ -139,6 +140,13 @@ def ensureAllVariablesAreSet(varDict):
         print('- WARNING - Both hyperGeom and hmm options are set to True... Set one option to "True" and the other '
               'to "False" or both to "False" in order to continue. Exiting...')
         return True
+    if varDict["hyperGeom"] is not True:
+        # Not in the reference: its hmm = True / both-False paths need hmmlearn's stochastic EM (scaffoldToChromosomes.py:
+        # 730-942; SURVEY.md section 2 row 7, out of scope).  Said here, before any part has touched a file, instead
+        # of as a NotImplementedError in the middle of Part 1.
+        print('- ERROR - this MI355X build implements the hyperGeom = True boundary finder only (hmm = True needs '
+              'hmmlearn; see README.md). Set "hyperGeom = True" and "hmm = False" to continue. Exiting...')
+        return True
     return False
 
 
@@ -158,19 +166,24 @@ def main(argv=None):
     v = readConfigFileToVariables(args.config)
     if ensureAllVariablesAreSet(v):
         sys.exit()
+    resident = None
     if args.part1:
         from . import scaffoldToChromosomes as part1
-        part1.runPipeline(v["hicProBedFile"], v["hicProBiasFile"], v["hicProMatrixFile"], v["hicProScaffSizeFile"],
-                          v["dendrogramOrderFile"], v["avgClusterPlot"], v["avgClusterPlot_outlined"],
-                          v["binGroupFile"], v["assessmentFile"], v["chromosomeGroupFile"],
-                          v["hyperGeom"], v["hmm"], v["minSize"], v["modularity"], v["louvainRounds"],
-                          v["psig"], v["convergenceRounds"], v["lookAhead"], v["resolution"], device=args.device)
+        # -part1 -part2 in one run: the contact matrix stays in HBM for Part 2 (the reference parses the text matrix a
+        # second time, OG:688-690; HICMI_REPARSE_FOR_PART2=1 does that too)
+        keep = bool(args.part2) and not os.environ.get("HICMI_REPARSE_FOR_PART2")
+        resident = part1.runPipeline(v["hicProBedFile"], v["hicProBiasFile"], v["hicProMatrixFile"], v["hicProScaffSizeFile"],
+                                     v["dendrogramOrderFile"], v["avgClusterPlot"], v["avgClusterPlot_outlined"],
+                                     v["binGroupFile"], v["assessmentFile"], v["chromosomeGroupFile"],
+                                     v["hyperGeom"], v["hmm"], v["minSize"], v["modularity"], v["louvainRounds"],
+                                     v["psig"], v["convergenceRounds"], v["lookAhead"], v["resolution"], device=args.device,
+                                     keep_resident=keep)
     if args.part2:
         from . import orderGenome as part2
         part2.runPipeline(v["hicProBedFile"], v["hicProBiasFile"], v["hicProMatrixFile"], v["chromosomeGroupFile"],
                           v["chromosomeOrderFile"], v["savePlotsDirectory"], v["chromosomePlotSuffix"],
                           v["fullGenomePlot"], v["fullGenomePlotTitle"], v["plotOrderFile"],
-                          v["nScaffolds"], v["scanScaffolds"], v["resolution"], device=args.device)
+                          v["nScaffolds"], v["scanScaffolds"], v["resolution"], device=args.device, resident=resident)
     if args.part3:
         from . import orientSmallScaffolds as part3
         part3.runPipeline(v["chromosomeOrderFile"], v["hicProScaffSizeFile"], v["restrictionSiteFile"], v["validPairFile"],

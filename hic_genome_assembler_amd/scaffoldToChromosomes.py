@@ -434,9 +434,11 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, hicProScaffSize
                 dendrogramOrderFile, avgClusterPlot, avgClusterPlot_outlined,
                 binGroupFile, assessmentFile, chromosomeGroupFile,
                 hyperGeom, hmm, minSize, modularity, louvainRounds,
-                psig, convergenceRounds, lookAhead, resolution, device=0, shard=None):
-    """S2C:1104-1174, same positional arguments (``device`` and ``shard`` are optional extras; ``shard=(rank, world)``:
-    this process is one of ``world`` that work on the same map, see runResident)."""
+                psig, convergenceRounds, lookAhead, resolution, device=0, shard=None, keep_resident=False):
+    """S2C:1104-1174, same positional arguments (``device``, ``shard`` and ``keep_resident`` are optional extras;
+    ``shard=(rank, world)``: this process is one of ``world`` that work on the same map, see runResident;
+    ``keep_resident=True``: the context with the contact matrix in HBM is not closed but returned as
+    ``(DeviceMatrix, bins of its rows)`` so that Part 2 of the same run need not parse the text matrix again)."""
     print("########################################")
     print("### Working on Part1 of the pipeline ###")
     t_all = time.time()
@@ -457,11 +459,15 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, hicProScaffSize
         if plotModule.plots_enabled(avgClusterPlot_outlined):
             plotModule.plotContactMap(plotModule.DeviceImage(adjMat.ctx, 1, adjMat.order), resolution=resolution,
                                       highlightChroms=cutIndices, showPlot=False, savePlot=avgClusterPlot_outlined)
-    finally:
+    except BaseException:
+        adjMat.ctx.close()
+        raise
+    if not keep_resident:
         adjMat.ctx.close()
     print("Total run-time of Part1 = " + str(time.time() - t_all))
     print("CutIndices = " + str(cutIndices))
     print("- Part 1 (grouping bins to groups) completed successfully")
+    return (adjMat, adjMat.kept_bins) if keep_resident else None
 
 
 def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOrderFile, binGroupFile,

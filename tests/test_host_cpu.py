@@ -107,6 +107,18 @@ def test_config_parser(tmp_path):
     v3 = run.readConfigFileToVariables(str(tmp_path / "c3.txt"))
     assert v3["hmm"] is True and v3["minSize"] == 5 and v3["chromosomePlotSuffix"] == " 500 Kb"
     assert run.ensureAllVariablesAreSet(v3) is True
+    # documented difference: hmm = True with hyperGeom = False (the reference's hmmlearn path, out of scope) is refused
+    # HERE, before any part runs - and a config line without ' = ' is skipped with a warning where the reference's
+    # parser raises IndexError: c3.txt above ended with such a line and still parsed
+    text = open(cfg).read().replace("hmm = False", "hmm = True").replace("hyperGeom = True", "hyperGeom = False")
+    (tmp_path / "c4.txt").write_text(text)
+    v4 = run.readConfigFileToVariables(str(tmp_path / "c4.txt"))
+    assert v4["hmm"] is True and v4["hyperGeom"] is False
+    assert run.ensureAllVariablesAreSet(v4) is True
+    with pytest.raises(SystemExit) as ex:
+        run.main(["-part1", "-c", str(tmp_path / "c4.txt")])
+    assert ex.value.code in (None, 0)                             # the reference's silent sys.exit() (RUN:270-271)
+    assert not os.path.exists(str(tmp_path / "o" / "dendrogramOrder.txt"))
 
 
 def test_loaders_match_oracle(tmp_path):

@@ -124,9 +124,16 @@ def test_valid_pair_scanner(tmp_path):
         idx, p1, p2, n_lines = _lib.scan_valid_pairs(str(big), names, pairs, threads)
         assert n_lines == len(rows) and list(zip(idx.tolist(), p1.tolist(), p2.tolist())) == want       # file order
     bad = tmp_path / "bad.txt"
-    bad.write_text("r\ta\t10\t+\tbb\n")
+    bad.write_text("r\ta\t10\t+\tbb\n")                         # five columns and a registered pair: cols[5] -> IndexError
     with pytest.raises(_lib.HicmiError):
         _lib.scan_valid_pairs(str(bad), names, pairs)
+    bad.write_text("r\ta\t10\t+\n")                              # four columns: cols[4] -> IndexError on any line
+    with pytest.raises(_lib.HicmiError):
+        _lib.scan_valid_pairs(str(bad), names, pairs)
+    short = tmp_path / "short.txt"                                # five columns, no registered pair: the reference never
+    short.write_text("r\ta\t10\t+\tzz\nr\ta\t3\t+\tbb\t4\n")     # touches cols[5] there (orientSmallScaffolds.py:168-170)
+    idx, p1, p2, n_lines = _lib.scan_valid_pairs(str(short), names, pairs)
+    assert n_lines == 2 and idx.tolist() == [0] and p1.tolist() == [3] and p2.tolist() == [4]
     bad.write_text("r\ta\t1x\t+\tbb\t3\t-\n")
     with pytest.raises(_lib.HicmiError):
         _lib.scan_valid_pairs(str(bad), names, pairs)
