@@ -192,13 +192,18 @@ class Job:
         dm = p1.DeviceMatrix(self.ctx)
         with contextlib.redirect_stdout(io.StringIO()):
             ta = time.perf_counter()
+            # Part 1's four text files are written by a background thread while the device works on (and while Part 2
+            # starts from the in-memory groups); finish_files() below is inside the timed step: all six files are on disk
+            # when it returns
             cuts = p1.runResident(dm, list(self.bins), self.sizes, f("dendrogramOrder.txt"), f("binGroups.txt"),
-                                  f("assessment.txt"), f("chromosomeGroups.txt"), 5, 0.0, .05, shard=self.shard)
+                                  f("assessment.txt"), f("chromosomeGroups.txt"), 5, 0.0, .05, shard=self.shard,
+                                  overlap_files=True)
             self.last["part1_s"] = time.perf_counter() - ta
             if not a.part1_only:
                 p2.runResident(p2.GenomeMatrix(self.ctx), dm.kept_bins, f("chromosomeGroups.txt"),
                                f("chromosomeOrders.txt"), f("plotOrder.txt"), a.n_scaffolds, a.scan_scaffolds,
-                               self.lay.resolution, shard=self.shard)
+                               self.lay.resolution, shard=self.shard, chromosomeList=dm.chromosome_groups)
+            dm.finish_files()
         self.last["part2_s"] = time.perf_counter() - ta - self.last["part1_s"]
         self.last["cuts"] = cuts
 

@@ -657,14 +657,17 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
     int rc = compute_sums(c);
     if (rc) return rc;
     const int64_t ldr = (n + 63) & ~(int64_t)63;
-    if (c->r_rows < n || c->ldr != ldr || !c->dR) {
+    // HICMI_SORT_BITONIC=1 (or HICMI_SORT_LDS=1): the earlier bitonic networks, which produce the argsort rows R and need
+    // the inversion pass; the default LSD radix kernel writes the rank rows directly
+    const bool bitonic = getenv("HICMI_SORT_BITONIC") != nullptr || getenv("HICMI_SORT_LDS") != nullptr;
+    if (c->r_rows < n || c->ldr != ldr || !c->dRank) {
         free_dev(c->dR); free_dev(c->dRank); free_dev(c->d_order); c->dR = c->dRank = nullptr; c->d_order = nullptr;
-        HIPCHK(hipMalloc((void**)&c->dR, sizeof(uint16_t) * (size_t)n * (size_t)ldr));
         HIPCHK(hipMalloc((void**)&c->dRank, sizeof(uint16_t) * (size_t)n * (size_t)ldr));
         HIPCHK(hipMalloc((void**)&c->d_order, sizeof(int32_t) * 2 * (size_t)n));       // [order][inverse order]
         c->ldr = ldr; c->r_rows = n;
     }
-    size_t need = sort_scratch_bytes((int)n);
+    if (bitonic && !c->dR) HIPCHK(hipMalloc((void**)&c->dR, sizeof(uint16_t) * (size_t)n * (size_t)ldr));
+    size_t need = bitonic ? sort_scratch_bytes((int)n) : sort_radix_scratch_bytes((int)n);
     if (need > c->sort_scratch_cap) {
         free_dev(c->d_sort_scratch); c->d_sort_scratch = nullptr; c->sort_scratch_cap = 0;
         HIPCHK(hipMalloc(&c->d_sort_scratch, need));
@@ -677,13 +680,17 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
         if (rc_up) return rc_up;
     }
     const double share = 1.0 / (double)c->shard_stride;             // this shard's rows only
-    {
+    if (!bitonic) {
         Timed t(c, F_SORT, (8.0 + 2.0) * (double)n * (double)n * share);
-        launch_sort_rows(c->dC, c->ldc, c->d_order, c->d_order + n, c->d_np, c->d_seq, (int)n, c->d_sort_scratch, c->dR, ldr,
-                         (int)c->shard_first, (int)c->shard_stride, c->stream);
-    }
-    HIPCHK(hipGetLastError());
-    {
+        launch_rank_rows_radix(c->dC, c->ldc, c->d_order, c->d_order + n, c->d_np, c->d_seq, (int)n, c->d_sort_scratch, c->dRank,
+                               ldr, (int)c->shard_first, (int)c->shard_stride, c->stream);
+    } else {
+        {
+            Timed t(c, F_SORT, (8.0 + 2.0) * (double)n * (double)n * share);
+            launch_sort_rows(c->dC, c->ldc, c->d_order, c->d_order + n, c->d_np, c->d_seq, (int)n, c->d_sort_scratch, c->dR, ldr,
+                             (int)c->shard_first, (int)c->shard_stride, c->stream);
+        }
+        HIPCHK(hipGetLastError());
         Timed t(c, F_RANK_INVERT, (2.0 + 2.0) * (double)n * (double)n * share);
         launch_rank_invert(c->dR, c->dRank, ldr, (int)n, (int)c->shard_first, (int)c->shard_stride, c->stream);
     }
@@ -700,10 +707,22 @@ int hicmi_get_rank_rows(hicmi_ctx* c, int64_t row0, int64_t nrows, int inverse, 
     if (!c->have_rank) return fail(HICMI_EINVAL, "hicmi_rank_matrix has not run");
     if (row0 + nrows > c->n) return fail(HICMI_EINVAL, "rows out of range");
     HIPCHK(hipSetDevice(c->device));
-    const uint16_t* src = (inverse ? c->dRank : c->dR) + row0 * c->ldr;
+    // the device keeps the RANK rows (position of every column); an argsort row is their inverse, formed here on request
+    const uint16_t* src = c->dRank + row0 * c->ldr;
     HIPCHK(hipMemcpy2DAsync(out, sizeof(uint16_t) * (size_t)c->n, src, sizeof(uint16_t) * (size_t)c->ldr,
                             sizeof(uint16_t) * (size_t)c->n, (size_t)nrows, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(sync_stream(c));
+    if (!inverse) {
+        std::vector<uint16_t> tmp((size_t)c->n);
+        for (int64_t r = 0; r < nrows; r++) {
+            uint16_t* row = out + r * c->n;
+            for (int64_t col = 0; col < c->n; col++) {
+                if (row[col] >= c->n) return fail(HICMI_ESTATE, "rank row %lld is not a permutation (a row of another shard?)", (long long)(row0 + r));
+                tmp[row[col]] = (uint16_t)col;
+            }
+            memcpy(row, tmp.data(), sizeof(uint16_t) * (size_t)c->n);
+        }
+    }
     return HICMI_OK;
 }
 

@@ -143,6 +143,10 @@ size_t sort_scratch_bytes(int n);             // device scratch (keys + indices)
 void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const int32_t* inv, const double* np_sum,
                       const double* seq_sum, int n, void* scratch, uint16_t* R, int64_t ldr, int row_first, int row_stride,
                       hipStream_t s);
+size_t sort_radix_scratch_bytes(int n);
+void launch_rank_rows_radix(const double* C, int64_t ldc, const int32_t* order, const int32_t* inv, const double* np_sum,
+                            const double* seq_sum, int n, void* scratch, uint16_t* rank, int64_t ldr, int row_first,
+                            int row_stride, hipStream_t s);   // LSD radix: writes the rank rows directly
 void launch_rank_invert(const uint16_t* R, uint16_t* rank, int64_t ldr, int n, int row_first, int row_stride, hipStream_t s);
 void launch_similarity_row(const double* C, int64_t ldc, const int32_t* order, const double* np_sum,
                            const double* seq_sum, int n, int row, double* out, hipStream_t s);

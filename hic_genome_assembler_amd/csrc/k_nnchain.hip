@@ -136,6 +136,69 @@ __device__ __forceinline__ ArgMinT argmint_wave(ArgMinT a)
     return m;
 }
 
+// The same result as argmint_wave for non-NaN values, in about a third of the instructions: first the minimum VALUE
+// (v_min_f64 over DPP moves - no compare-and-select on three registers per step), then the lowest INDEX among the lanes
+// that hold it (v_min_u32), then "is it attained more than once" as one ballot.  NaN never wins a v_min (IEEE minNum),
+// exactly as it never wins the `<` of argmint_join.  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ double fmin_dpp_step(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return fmin(v, __hiloint2double(ohi, olo));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned int umin_dpp_step(unsigned int v)
+{
+    const unsigned int o = (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ double readlane_f64(double v, int src)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+// rows: how many rows of 16 lanes take part (4 = the whole wave; 1 or 2: the first 16 / 32 lanes, each ROW reduced on its own
+// when per_row is set - used for the two results of the fused pass that sit in rows 0 and 1)
+__device__ __forceinline__ ArgMinT argmint_wave_fast(ArgMinT a)
+{
+    double m = a.v;
+    m = fmin_dpp_step<0xB1>(m); m = fmin_dpp_step<0x4E>(m); m = fmin_dpp_step<0x141>(m); m = fmin_dpp_step<0x140>(m);
+    const double m0 = readlane_f64(m, 0), m1 = readlane_f64(m, 16), m2 = readlane_f64(m, 32), m3 = readlane_f64(m, 48);
+    const double mv = fmin(fmin(m0, m1), fmin(m2, m3));
+    const bool at_min = a.v == mv;
+    unsigned int ix = at_min ? (unsigned int)a.i : 0xffffffffu;
+    ix = umin_dpp_step<0xB1>(ix); ix = umin_dpp_step<0x4E>(ix); ix = umin_dpp_step<0x141>(ix); ix = umin_dpp_step<0x140>(ix);
+    const unsigned int i0 = (unsigned int)__builtin_amdgcn_readlane((int)ix, 0), i1 = (unsigned int)__builtin_amdgcn_readlane((int)ix, 16);
+    const unsigned int i2 = (unsigned int)__builtin_amdgcn_readlane((int)ix, 32), i3 = (unsigned int)__builtin_amdgcn_readlane((int)ix, 48);
+    unsigned int mi = i0 < i1 ? i0 : i1;
+    const unsigned int mi2 = i2 < i3 ? i2 : i3;
+    mi = mi < mi2 ? mi : mi2;
+    ArgMinT r;
+    r.v = mv;
+    r.i = mi == 0xffffffffu ? 0x7fffffff : (int)mi;       // nothing compared (all NaN / no candidates)
+    r.t = __ballot(at_min && ((unsigned int)a.i != mi || a.t != 0)) != 0ull ? 1 : 0;
+    return r;
+}
+// the same per row of 16 lanes (result in every lane of its row): the cross-wave step of the reductions
+__device__ __forceinline__ ArgMinT argmint_row16_fast(ArgMinT a)
+{
+    double m = a.v;
+    m = fmin_dpp_step<0xB1>(m); m = fmin_dpp_step<0x4E>(m); m = fmin_dpp_step<0x141>(m); m = fmin_dpp_step<0x140>(m);
+    const bool at_min = a.v == m;
+    unsigned int ix = at_min ? (unsigned int)a.i : 0xffffffffu;
+    ix = umin_dpp_step<0xB1>(ix); ix = umin_dpp_step<0x4E>(ix); ix = umin_dpp_step<0x141>(ix); ix = umin_dpp_step<0x140>(ix);
+    // tie: some lane of the row holds the minimum at another index, or its own flag is set
+    unsigned int tf = (at_min && ((unsigned int)a.i != ix || a.t != 0)) ? 1u : 0u;
+    tf |= (unsigned int)__builtin_amdgcn_update_dpp((int)tf, (int)tf, 0xB1, 0xf, 0xf, false);
+    tf |= (unsigned int)__builtin_amdgcn_update_dpp((int)tf, (int)tf, 0x4E, 0xf, 0xf, false);
+    tf |= (unsigned int)__builtin_amdgcn_update_dpp((int)tf, (int)tf, 0x141, 0xf, 0xf, false);
+    tf |= (unsigned int)__builtin_amdgcn_update_dpp((int)tf, (int)tf, 0x140, 0xf, 0xf, false);
+    ArgMinT r;
+    r.v = m; r.i = ix == 0xffffffffu ? 0x7fffffff : (int)ix; r.t = (int)tf;
+    return r;
+}
+
 // workspace layout (all 16-byte aligned)
 struct NNWorkspace {
     int* state;                 // [0] step [1] len [2] top [3] second [4] first_ptr [5] stop code [6] n_dirty [7] n after compaction
@@ -1231,7 +1294,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
                 s_act = act; s_x = top; s_prev = (len > 1) ? second : -1; s_tx = -1;
                 if (act == 1) {
                     xbit = smask[top >> 5] & (1u << (top & 31));
-                    smask[top >> 5] &= ~xbit;
+                    atomicAnd(&smask[top >> 5], ~xbit);
                     s_cnt[1]++; s_cnt[0] += (unsigned long long)(total_steps + 1 - step);
                 }
             }
@@ -1291,14 +1354,14 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
                 if (cd == prev) s_dprev = v;
             }
             if (cand.i != 0x7fffffff) best = argmint_join(best, cand.v, cand.i, 0);
-            best = argmint_wave(best);
+            best = argmint_wave_fast(best);
             if (lane == 0) { s_v[wave] = best.v; s_i[wave] = best.i; s_t[wave] = best.t; }
             __syncthreads();
             if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[1] += t1 - t0; t0 = t1; }
             xseq++;
             if (wave == 0) {
                 ArgMinT m = {lane < 16 ? s_v[lane] : __builtin_inf(), lane < 16 ? s_i[lane] : 0x7fffffff, lane < 16 ? s_t[lane] : 0};
-                m = argmint_row16(m);                               // this slice's result, in every lane of row 0
+                m = argmint_row16_fast(m);                               // this slice's result, in every lane of row 0
                 u32x4* slots = mail + (xseq & 1u) * (NN_MAXWG * 2);
                 if (lane == 0) st16_sc1(slots + wg * 2, mwc_pack(m.v, m.i, m.t, 0, xseq));
                 ArgMinT o = {__builtin_inf(), 0x7fffffff, 0};
@@ -1315,14 +1378,14 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
                 }
                 if (inject_late > 0 && (int)xseq == inject_late) late = 1;      // test hook: a peer that never answers
                 late = __any(late);
-                m = argmint_row16(o);
+                m = argmint_row16_fast(o);
                 if (lane == 0) {
-                    smask[x >> 5] |= xbit;
+                    atomicOr(&smask[x >> 5], xbit);
                     if (late) { s_stop = NN_STOP_LATE; stop_code = NN_STOP_LATE; }
                     else if (m.i < 0 || m.i >= n) { s_stop = NN_STOP_GUARD; stop_code = NN_STOP_GUARD; }
                     else {
                         nnidx[x] = (uint16_t)m.i;
-                        if (m.t) tieb[x >> 5] |= (1u << (x & 31)); else tieb[x >> 5] &= ~(1u << (x & 31));
+                        if (m.t) atomicOr(&tieb[x >> 5], 1u << (x & 31)); else atomicAnd(&tieb[x >> 5], ~(1u << (x & 31)));
                         if (x >= c0 && x < c1) w.nnval[x] = m.v;        // the owner of column x keeps the distance
                         int y = m.i;
                         if (prev >= 0 && !(m.v < s_dprev)) y = prev;    // SciPy: the previous element wins unless STRICTLY closer
@@ -1348,8 +1411,8 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
             int nx = lsize[xx], ny = lsize[yy];
             lsize[xx] = 0;
             lsize[yy] = (uint16_t)(nx + ny);
-            alive[xx >> 5] &= ~(1u << (xx & 31));
-            smask[xx >> 5] &= ~(1u << (xx & 31));
+            atomicAnd(&alive[xx >> 5], ~(1u << (xx & 31)));
+            atomicAnd(&smask[xx >> 5], ~(1u << (xx & 31)));
             s_mx = xx; s_my = yy; s_nx = nx; s_ny = ny; s_tx = -1; s_ty = -1; s_ey = -1; s_ta = -1;
             // entries no push of this epoch has overwritten live in workgroup 0's copy (saved by the last epoch)
             if (len < lowmark) lowmark = len;
@@ -1426,12 +1489,23 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
                 if (first) {
                     // while the loads are in flight: every replica drops "my neighbour is x or y" for the rows outside its
                     // slice (LDS only; the own slice is handled with the streamed / gathered values below)
-                    for (int i = tid * 2; i < n; i += 2 * NN_THREADS) {
-                        if (i >= c0 && i < c1) continue;
-                        const uint32_t ip = *reinterpret_cast<const uint32_t*>(nnidx + i);
-                        const uint32_t i0 = ip & 0xffffu, i1 = ip >> 16;
-                        if (i0 == (uint32_t)mx || i0 == (uint32_t)my) nnidx[i] = (uint16_t)NN_NOIDX;
-                        if (i1 == (uint32_t)mx || i1 == (uint32_t)my) nnidx[i + 1] = (uint16_t)NN_NOIDX;
+                    // eight entries per 16-byte LDS read; a word can only matter if one of its halves equals x or y, which the
+                    // zero-halfword test on (word XOR pattern) finds without unpacking (it never misses; a rare false hit only
+                    // costs the exact compare)
+                    const uint32_t px = (uint32_t)mx * 0x00010001u, py = (uint32_t)my * 0x00010001u;
+                    for (int i = tid * 8; i < n; i += 8 * NN_THREADS) {
+                        if (i >= c0 && i < c1) continue;                 // slices are multiples of 64 columns: never straddled
+                        const uint4 v = *reinterpret_cast<const uint4*>(nnidx + i);
+                        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const uint32_t tx2 = wv[u] ^ px, ty2 = wv[u] ^ py;
+                            if ((((tx2 - 0x00010001u) & ~tx2) | ((ty2 - 0x00010001u) & ~ty2)) & 0x80008000u) {
+                                const uint32_t i0 = wv[u] & 0xffffu, i1 = wv[u] >> 16;
+                                if (i0 == (uint32_t)mx || i0 == (uint32_t)my) nnidx[i + 2 * u] = (uint16_t)NN_NOIDX;
+                                if (i1 == (uint32_t)mx || i1 == (uint32_t)my) nnidx[i + 2 * u + 1] = (uint16_t)NN_NOIDX;
+                            }
+                        }
                     }
                     if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[9] += t1 - t0; t0 = t1; }
                 }
@@ -1499,8 +1573,8 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
             }
             if (ev) s_ev = 1;
             if (acand.i != 0x7fffffff) abest = argmint_join(abest, acand.v, acand.i, acand.t);
-            rbest = argmint_wave(rbest);
-            abest = argmint_wave(abest);
+            rbest = argmint_wave_fast(rbest);
+            abest = argmint_wave_fast(abest);
             if (lane == 0) { s_v[wave] = rbest.v; s_i[wave] = rbest.i; s_t[wave] = rbest.t; s_v[16 + wave] = abest.v; s_i[16 + wave] = abest.i; s_t[16 + wave] = abest.t; }
             if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[12] += t1 - t0; t0 = t1; }
             if (tid == NN_THREADS - 1) {
@@ -1523,7 +1597,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
             xseq++;
             if (wave == 0) {
                 ArgMinT m = {lane < 32 ? s_v[lane] : __builtin_inf(), lane < 32 ? s_i[lane] : 0x7fffffff, lane < 32 ? s_t[lane] : 0};
-                m = argmint_row16(m);                               // lanes 0-15: new row, lanes 16-31: row a (this slice)
+                m = argmint_row16_fast(m);                               // lanes 0-15: new row, lanes 16-31: row a (this slice)
                 u32x4* slots = mail + (xseq & 1u) * (NN_MAXWG * 2);
                 if (lane == 0) st16_sc1(slots + wg * 2, mwc_pack(m.v, m.i, m.t, s_ev, xseq));
                 if (lane == 16) st16_sc1(slots + wg * 2 + 1, mwc_pack(m.v, m.i, m.t, 0, xseq));
@@ -1544,7 +1618,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
                 if (inject_late > 0 && (int)xseq == inject_late) late = 1;
                 late = __any(late);
                 const unsigned long long evm = __ballot(evbit != 0);
-                m = argmint_row16(o);
+                m = argmint_row16_fast(o);
                 const double av = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m.v), 16), __builtin_amdgcn_readlane(__double2loint(m.v), 16));
                 const int ai = __builtin_amdgcn_readlane(m.i, 16), at = __builtin_amdgcn_readlane(m.t, 16);
                 if (lane == 0) {
@@ -1570,17 +1644,17 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
                 // cluster y is dirty from now on; its neighbour is known
                 if (s_ey >= 0) dslot[s_ey] = -1;
                 dslot[D] = my; dtime[D] = step;
-                smask[my >> 5] &= ~(1u << (my & 31));
+                atomicAnd(&smask[my >> 5], ~(1u << (my & 31)));
                 if (s_my_i >= 0 && s_my_i < n) {
                     nnidx[my] = (uint16_t)s_my_i;
-                    if (s_my_t) tieb[my >> 5] |= (1u << (my & 31)); else tieb[my >> 5] &= ~(1u << (my & 31));
+                    if (s_my_t) atomicOr(&tieb[my >> 5], 1u << (my & 31)); else atomicAnd(&tieb[my >> 5], ~(1u << (my & 31)));
                     if (my >= c0 && my < c1) w.nnval[my] = s_my_v;
                 } else nnidx[my] = (uint16_t)NN_NOIDX;
                 if (a >= 0) {                                      // the fused scan of row a: same decision as a scan on its own
                     if (s_a_i < 0 || s_a_i >= n) { s_stop = NN_STOP_GUARD; stop_code = NN_STOP_GUARD; }
                     else {
                         nnidx[a] = (uint16_t)s_a_i;
-                        if (s_a_t) tieb[a >> 5] |= (1u << (a & 31)); else tieb[a >> 5] &= ~(1u << (a & 31));
+                        if (s_a_t) atomicOr(&tieb[a >> 5], 1u << (a & 31)); else atomicAnd(&tieb[a >> 5], ~(1u << (a & 31)));
                         if (a >= c0 && a < c1) w.nnval[a] = s_a_v;
                         int y = s_a_i;
                         if (aprev >= 0 && !(s_a_v < s_dprev)) y = aprev;

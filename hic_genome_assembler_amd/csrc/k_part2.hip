@@ -9,6 +9,8 @@
 // sub-matrix through the permutation, which sits in LDS.  fp64 throughout; one workgroup per
 // candidate with a fixed reduction order, so identical index lists give bit-identical scores and
 // the reference's first-strict-maximum tie-breaking (OG:349,359,464,535) is preserved on the host.
+#include <cstdlib>
+
 #include "hicmi_internal.h"
 
 namespace hicmi {
@@ -130,15 +132,43 @@ __device__ __forceinline__ double diag_sum_body(const double* __restrict__ M2, i
     return acc;
 }
 
+// The same diagonal as NUMBA sums it.  Under a real Numba install costFunction_numba (orderGenome.py:184-191) is
+// compiled in nopython mode, where numpy.trace is Numba's own np_trace: `ret = 0; for i in range(n): ret += a[i, k + i]`,
+// a strictly sequential loop - not NumPy's pairwise add.reduce.  The scores differ in the last bits (<= 1e-15 relative),
+// which can decide a `cost > bestCost`.  HICMI_P2_TRACE_ORDER=numba selects this order for the candidates' scores; the
+// totals (OG:343,448,506) are computed outside the jitted function and stay NumPy's.  Parity unpinned: Numba is not
+// installed here; tests/golden/n160_numba was produced with that loop patched into the shimmed reference.
+__device__ __forceinline__ double diag_sum_sequential(const double* __restrict__ M2, int64_t ld2, const IndexMap& m, int n_used,
+                                                      int off)
+{
+    __shared__ double seq_buf[1024];
+    const int lane = threadIdx.x, len = n_used - off;
+    double acc = 0.0;
+    for (int c0 = 0; c0 < len; c0 += 1024) {
+        const int cnt = len - c0 < 1024 ? len - c0 : 1024;
+        __syncthreads();
+        for (int e = lane; e < cnt; e += 64) seq_buf[e] = M2[(int64_t)m.at(c0 + e) * ld2 + m.at(c0 + e + off)];
+        __syncthreads();
+        if (lane == 0) acc = serial_sum_lds(seq_buf, 0, cnt, acc);
+    }
+    return acc;
+}
+
+static bool numba_trace_order()
+{
+    const char* v = getenv("HICMI_P2_TRACE_ORDER");
+    return v && (v[0] == 'n' || v[0] == 'N') && (v[1] == 'u' || v[1] == 'U') && (v[2] == 'm' || v[2] == 'M') && (v[3] == 'b' || v[3] == 'B');
+}
+
 // T[cand][off] for off = 1..n_used-1 (T[cand][0] unused).  perms == nullptr: the identity order.
 __global__ __launch_bounds__(64) void k_p2_diag_sums(const double* __restrict__ M2, int64_t ld2,
                                                      const int32_t* __restrict__ perms, int n_used,
-                                                     double* __restrict__ T)
+                                                     double* __restrict__ T, int sequential)
 {
     const int cand = blockIdx.y, off = diag_of_block(blockIdx.x);
     if (off >= n_used) return;
     const IndexMap m = {perms ? perms + (int64_t)cand * n_used : nullptr, kNoSplice, 0, 0, 0};
-    const double acc = diag_sum_body(M2, ld2, m, n_used, off);
+    const double acc = sequential ? diag_sum_sequential(M2, ld2, m, n_used, off) : diag_sum_body(M2, ld2, m, n_used, off);
     if (threadIdx.x == 0) T[(int64_t)cand * n_used + off] = acc;
 }
 
@@ -208,7 +238,7 @@ static size_t serial_lds_bytes(int n) { return n <= SERIAL_LDS_MAX ? (((size_t)n
 
 void launch_p2_total(const double* M2, int64_t ld2, int n, double* T, double* total, hipStream_t s)
 {
-    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n), 1), dim3(64), 0, s, M2, ld2, (const int32_t*)nullptr, n, T);
+    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n), 1), dim3(64), 0, s, M2, ld2, (const int32_t*)nullptr, n, T, 0);
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_total_exact), g_lds_total, 65536);
     hipLaunchKernelGGL(k_p2_total_exact, dim3(1), dim3(256), serial_lds_bytes(n), s, T, n, total);
 }
@@ -216,7 +246,7 @@ void launch_p2_total(const double* M2, int64_t ld2, int n, double* T, double* to
 void launch_p2_total_perm(const double* M2, int64_t ld2, const int32_t* d_perm, int n, double* T, double* total,
                           hipStream_t s)
 {
-    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n), 1), dim3(64), 0, s, M2, ld2, d_perm, n, T);
+    if (n > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n), 1), dim3(64), 0, s, M2, ld2, d_perm, n, T, 0);
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_total_exact), g_lds_total, 65536);
     hipLaunchKernelGGL(k_p2_total_exact, dim3(1), dim3(256), serial_lds_bytes(n), s, T, n, total);
 }
@@ -226,7 +256,8 @@ void launch_p2_score_exact(const double* M2, int64_t ld2, const int32_t* perms, 
                            double* T, double* work, double* scores, hipStream_t s)
 {
     if (n_cand <= 0) return;
-    if (n_used > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n_used), n_cand), dim3(64), 0, s, M2, ld2, perms, n_used, T);
+    if (n_used > 1) hipLaunchKernelGGL(k_p2_diag_sums, dim3(diag_grid(n_used), n_cand), dim3(64), 0, s, M2, ld2, perms, n_used, T,
+                                       numba_trace_order() ? 1 : 0);
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_p2_cost_exact), g_lds_cost, 65536);
     hipLaunchKernelGGL(k_p2_cost_exact, dim3(n_cand), dim3(256), serial_lds_bytes(n_used), s, T, n_used, total, work, scores);
 }
@@ -235,7 +266,7 @@ void launch_p2_score_exact(const double* M2, int64_t ld2, const int32_t* perms, 
 // The literal pass of a step, run only for chromosomes whose short list needs it (k_insb_shortlist):
 // diagonal sums of "arrangement, then the new scaffold forward" (OG:484-487 -> OG:343: T_total, the step's total)
 // and of the short-listed candidates (each workgroup walks the few of its chromosome)
-__global__ __launch_bounds__(64) void k_insb_diag_cand(const InsStep* __restrict__ steps)
+__global__ __launch_bounds__(64) void k_insb_diag_cand(const InsStep* __restrict__ steps, int sequential)
 {
     const InsStep& d = steps[blockIdx.y];
     if (!d.active || d.st->fail >= 0) return;
@@ -250,7 +281,7 @@ __global__ __launch_bounds__(64) void k_insb_diag_cand(const InsStep* __restrict
     }
     for (int q = 0; q < ns; q++) {
         const IndexMap m = {d.pos_cur, d.packed_cur[d.S + d.st->gap[q]], d.L, d.new_start, d.st->rev[q]};
-        const double acc = diag_sum_body(d.M2, d.ld2, m, n_used, off);
+        const double acc = sequential ? diag_sum_sequential(d.M2, d.ld2, m, n_used, off) : diag_sum_body(d.M2, d.ld2, m, n_used, off);
         if (threadIdx.x == 0) d.T_cand[(int64_t)q * n_used + off] = acc;
     }
 }
@@ -288,7 +319,7 @@ __global__ __launch_bounds__(256) void k_insb_cost(const InsStep* __restrict__ s
 void launch_insb_diag_cand(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s)
 {
     if (max_n_used < 2) return;
-    hipLaunchKernelGGL(k_insb_diag_cand, dim3(diag_grid(max_n_used), n_chrom), dim3(64), 0, s, steps);
+    hipLaunchKernelGGL(k_insb_diag_cand, dim3(diag_grid(max_n_used), n_chrom), dim3(64), 0, s, steps, numba_trace_order() ? 1 : 0);
 }
 
 void launch_insb_cost(const InsStep* steps, int n_chrom, int max_n_used, hipStream_t s)

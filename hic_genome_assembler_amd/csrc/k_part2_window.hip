@@ -15,6 +15,8 @@
 //
 // Only differences between candidates of a step reach a decision, and the winners are re-scored literally
 // (k_p2_diag_sums), so the summation order of these tables never reaches an output.
+#include <cstdlib>
+
 #include "hicmi_internal.h"
 
 namespace hicmi {
@@ -103,6 +105,115 @@ __global__ __launch_bounds__(256) void k_win_outside(const double* __restrict__ 
                 Q[((int64_t)(e >> (k - 1)) << k) | spread_bit(e & ((1 << (k - 1)) - 1), j)] = sum;
         }
     }
+}
+
+// ---- Q on the matrix cores --------------------------------------------------------------------------------------
+// The same table as k_win_outside, formed through the dense product behind it (the results-neutral
+// contraction of this path; the north_star's "row x row^T similarity" does not exist in the reference):
+//     G[i][s] = sum over outside positions q of  M[row i of scaffold j][column at q] * w(|p0 + s - pos(q)|),   s = 0 .. m-1
+// i.e. G = A (L_j x n_out) . T (n_out x m) with the Toeplitz decay T[q][s] = H[n-1] - H[|p0 + s - pos(q)| - 1] generated on
+// the fly from H, on v_mfma_f64_16x16x4_f64 (A: one f64 per lane, row = lane & 15, k = lane >> 4; B: k = lane >> 4,
+// column = lane & 15; C/D: four f64 per lane, row = (lane >> 4) + 4 r, column = lane & 15).  A table entry is then a
+// diagonal of G:  Q[j][rev][B] = sum_i G[i][glen(B) + (rev ? L_j - 1 - i : i)].
+// Workgroup = (scaffold j, window, slice of the outside positions); 16-row tiles of A are staged through LDS 64 columns at
+// a time (coalesced along q), wave w accumulates the slot tiles w, w + 4, ...; fp64 throughout.  Every entry is a
+// different summation order than the vector-ALU kernel's: neither reaches an output (winners are re-scored literally).
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+static constexpr int WM_QC = 64;                          // outside positions staged per trip
+static constexpr int WM_MAX_TILES = 8;                    // slot tiles per wave: windows up to 4 * 8 * 16 = 512 bins
+
+template <bool H_IN_LDS>
+__global__ __launch_bounds__(256) void k_win_outside_mfma(const double* __restrict__ M2, int64_t ld2,
+                                                          const int32_t* __restrict__ pos2sel, int n, int k,
+                                                          const WindowBatchEntry* __restrict__ wb, const double* H,
+                                                          double* __restrict__ tables, int64_t table_stride, int m_pad_max)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+    double* As = reinterpret_cast<double*>(smem_w);                          // [16][WM_QC + 1]
+    double* Gt = As + 16 * (WM_QC + 1);                                       // [16][m_pad_max]
+    __shared__ int s_len[8], s_glen[256], s_pos[WM_QC], s_col[WM_QC];
+    const WindowBatchEntry& we = wb[blockIdx.y];
+    const int j = blockIdx.x, p0 = we.p0, m = we.m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < k) s_len[tid] = we.w.len[tid];
+    const double hn = H[n - 1];
+    if (H_IN_LDS) {
+        double* hl = Gt + 16 * m_pad_max;
+        for (int i = tid; i < n; i += 256) hl[i] = H[i];
+        H = hl;
+    }
+    __syncthreads();
+    if (tid < (1 << k)) {
+        int g = 0;
+        for (int b = 0; b < k; b++) if ((tid >> b) & 1) g += s_len[b];
+        s_glen[tid] = g;
+    }
+    __syncthreads();
+    const int Lj = s_len[j], startj = we.w.start[j], n_out = n - m;
+    const int q_lo = (int)(((int64_t)blockIdx.z * n_out) / WT_SLICES), q_hi = (int)(((int64_t)(blockIdx.z + 1) * n_out) / WT_SLICES);
+    double* __restrict__ Q = tables + (int64_t)blockIdx.y * table_stride + blockIdx.z * wt_q_size(k) + (((int64_t)j * 2) << k);
+    const int n_entries = 2 << (k - 1);                     // (orientation, set of the other k-1 scaffolds): <= 256
+    const int m_pad = (m + 15) & ~15, n_tiles = m_pad >> 4;
+    // this thread's table entry (threads >= n_entries idle in the reduction)
+    const int e_rev = tid < n_entries ? tid >> (k - 1) : 0;
+    const int e_off = tid < n_entries ? s_glen[spread_bit(tid & ((1 << (k - 1)) - 1), j)] : 0;
+    double qacc = 0.0;
+    for (int r0 = 0; r0 < Lj; r0 += 16) {
+        mfma_d4 acc[WM_MAX_TILES];
+#pragma unroll
+        for (int t = 0; t < WM_MAX_TILES; t++) acc[t] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+        for (int qc = q_lo; qc < q_hi; qc += WM_QC) {
+            __syncthreads();                                // the previous trip's fragments have been read
+            if (tid < WM_QC) {
+                const int qq = qc + tid;
+                const int pos = qq < q_hi ? (qq < p0 ? qq : qq + m) : -1;      // positions outside the window keep their place
+                s_pos[tid] = pos;
+                s_col[tid] = pos >= 0 ? pos2sel[pos] : 0;
+            }
+            __syncthreads();
+            for (int e = tid; e < 16 * WM_QC; e += 256) {   // 16 rows x 64 columns, coalesced along q
+                const int r = e / WM_QC, c = e - r * WM_QC;
+                const bool ok = r0 + r < Lj && s_pos[c] >= 0;
+                As[r * (WM_QC + 1) + c] = ok ? M2[(int64_t)(startj + r0 + r) * ld2 + s_col[c]] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int kk = 0; kk < WM_QC / 4; kk++) {
+                const int kq = kk * 4 + (lane >> 4);
+                const double a = As[(lane & 15) * (WM_QC + 1) + kq];
+                const int pos = s_pos[kq];
+#pragma unroll
+                for (int t = 0; t < WM_MAX_TILES; t++) {
+                    const int st = wave + 4 * t;
+                    if (st < n_tiles) {                     // uniform per wave
+                        int d = p0 + st * 16 + (lane & 15) - pos;
+                        d = d < 0 ? -d : d;
+                        d = d < 1 ? 1 : (d > n - 1 ? n - 1 : d);    // padded rows / columns carry a == 0: any finite weight does
+                        const double b = hn - H[d - 1];
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < WM_MAX_TILES; t++) {
+            const int st = wave + 4 * t;
+            if (st < n_tiles) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) Gt[((lane >> 4) + 4 * r) * m_pad_max + st * 16 + (lane & 15)] = acc[t][r];
+            }
+        }
+        __syncthreads();
+        if (tid < n_entries) {
+            const int rows = Lj - r0 < 16 ? Lj - r0 : 16;
+            for (int r = 0; r < rows; r++) {
+                const int i = r0 + r;
+                qacc += Gt[r * m_pad_max + e_off + (e_rev ? Lj - 1 - i : i)];
+            }
+        }
+    }
+    if (tid < n_entries) Q[((int64_t)e_rev << k) | spread_bit(tid & ((1 << (k - 1)) - 1), j)] = qacc;
 }
 
 // ---- P: window scaffold a placed before b; C: pairs inside one scaffold ------------------------------------------
@@ -219,7 +330,7 @@ __global__ __launch_bounds__(256) void k_win_candidates(int k, const int8_t* __r
     delta_all[(int64_t)blockIdx.y * n_cand + c] = sum;
 }
 
-static std::atomic<int> g_lds_out{0}, g_lds_pairs{0};
+static std::atomic<int> g_lds_out{0}, g_lds_pairs{0}, g_lds_mfma{0}, g_lds_mfma2{0};
 
 // tables: n_win * window_table_doubles(k) doubles of scratch; delta_all: n_win x (n_ord * n_ori)
 void launch_p2_window_tables(const double* M2, int64_t ld2, const int32_t* pos2sel, int n, int k,
@@ -230,7 +341,23 @@ void launch_p2_window_tables(const double* M2, int64_t ld2, const int32_t* pos2s
     const int64_t stride = window_table_doubles(k);
     const size_t h_all = (((size_t)n * sizeof(double)) + 15) & ~(size_t)15;
     const size_t h_win = (((size_t)max_m * sizeof(double)) + 15) & ~(size_t)15;
-    if (h_all <= 96 * 1024) {
+    // the outside table through the matrix cores (v_mfma_f64_16x16x4_f64) for windows of up to 512 bins and at most 256
+    // table entries per scaffold (k <= 8); HICMI_P2_WINDOW_VALU=1 keeps the vector-ALU kernel (A/B)
+    const int m_pad_max = (max_m + 15) & ~15;
+    const size_t lds_mfma = ((size_t)16 * (WM_QC + 1) + (size_t)16 * m_pad_max) * sizeof(double);
+    static const bool valu_only = getenv("HICMI_P2_WINDOW_VALU") != nullptr;
+    if (!valu_only && m_pad_max <= 16 * 4 * WM_MAX_TILES && k <= 8 && lds_mfma <= 96 * 1024) {
+        if (lds_mfma + h_all <= 144 * 1024) {
+            ensure_dynamic_lds(reinterpret_cast<const void*>(k_win_outside_mfma<true>), g_lds_mfma, lds_mfma + h_all);
+            hipLaunchKernelGGL(k_win_outside_mfma<true>, dim3(k, n_win, WT_SLICES), dim3(256), lds_mfma + h_all, s, M2, ld2, pos2sel, n, k,
+                               wb, H, tables, stride, m_pad_max);
+        } else {
+            ensure_dynamic_lds(reinterpret_cast<const void*>(k_win_outside_mfma<false>), g_lds_mfma2, lds_mfma);
+            hipLaunchKernelGGL(k_win_outside_mfma<false>, dim3(k, n_win, WT_SLICES), dim3(256), lds_mfma, s, M2, ld2, pos2sel, n, k, wb,
+                               H, tables, stride, m_pad_max);
+        }
+    }
+    else if (h_all <= 96 * 1024) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(k_win_outside<true>), g_lds_out, h_all);
         hipLaunchKernelGGL(k_win_outside<true>, dim3(k, n_win, WT_SLICES), dim3(256), h_all, s, M2, ld2, pos2sel, n, k, wb, H, tables, stride);
     } else {

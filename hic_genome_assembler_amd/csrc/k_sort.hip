@@ -309,7 +309,245 @@ __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
     }
 }
 
-// order: leaf order (row r of the result is storage row order[r]); inv: its inverse (position of a storage column)
+// ---- LSD radix sort ---------------------------------------------------------------------------------------------
+// The bitonic networks above do O(n log^2 n) compare-exchanges on 64-bit keys: 105 stages for a 16384-element row, and
+// rows beyond one tile go through global scratch at every merge level.  This kernel sorts (key, column) ascending by
+// LSD radix, 4 bits per pass: the 16 bits of the column first (the tie rule: equal keys by ascending column), then the
+// key digits that actually vary in the row (OR / AND of the row's keys: sign and high exponent bits never do).
+// A lane keeps 16 consecutive elements in registers; a pass is
+//   count the lane's digits (packed 8-bit counters, which also give each element its rank among the lane's equals),
+//   per-lane counts -> LDS, digit-major [16][1024]; an exclusive scan over that array (each lane 16 consecutive entries,
+//   wave scan, 16 wave totals) turns them into the lane's first output slot per digit,
+//   scatter: the three components (key high, key low, column) go through LDS to their slots and are read back 16
+//   consecutive per lane - stable, so the passes compose.
+// ~18 passes x ~400 instructions instead of 105 stages x ~300.  Output: the RANK row directly - rank[row][col] =
+// position of col in descending similarity (ties: larger column first) - scattered into an LDS image of the row and
+// written with 16-byte stores; the argsort row itself (R) is never materialised (hicmi_get_rank_rows inverts a rank
+// row on demand).  Rows longer than one 16384-element tile: every tile is sorted, parked in the workgroup's scratch,
+// and an element's final position is its position in its own tile plus its lower bound in every other tile (one
+// binary search per lane and tile, then a forward walk: the lane's 16 elements are consecutive, so are their bounds).
+static constexpr int RX_T = 1024, RX_E = 8, RX_TILE = RX_T * RX_E;      // 8 elements per lane: 16 would not fit 128 registers
+static constexpr size_t RX_CNT = 32768, RX_STAGE = (size_t)RX_TILE * 4, RX_STIDX = (size_t)RX_TILE * 2;
+static constexpr size_t RX_LDS = RX_CNT + RX_STAGE + RX_STIDX;            // 80 KB: two workgroups per CU
+
+__device__ __forceinline__ bool rx_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) { return ka < kb || (ka == kb && ia < ib); }
+
+__global__ __launch_bounds__(RX_T) void k_sort_rows_radix(
+    const double* __restrict__ C, int64_t ldc, const int32_t* __restrict__ order, const double* __restrict__ np_sum,
+    const double* __restrict__ seq_sum, int n, uint64_t* __restrict__ skeys, uint16_t* __restrict__ sidx,
+    uint16_t* __restrict__ rank, int64_t ldr, const int32_t* __restrict__ inv, int row_first, int row_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* cnt = reinterpret_cast<uint16_t*>(smem);                       // [16][RX_T]
+    uint32_t* stage = reinterpret_cast<uint32_t*>(smem + RX_CNT);            // [RX_TILE]
+    uint16_t* stidx = reinterpret_cast<uint16_t*>(smem + RX_CNT + RX_STAGE); // [RX_TILE]
+    uint16_t* image = reinterpret_cast<uint16_t*>(smem);                     // [n] in the last phase (aliases everything)
+    __shared__ uint32_t s_wsum[16];
+    __shared__ unsigned long long s_or[16], s_and[16];
+    const int tid0 = threadIdx.x, lane = tid0 & 63, wave = tid0 >> 6;
+    const int ntiles = (n + RX_TILE - 1) / RX_TILE;
+    uint64_t* gk = skeys + (size_t)blockIdx.x * (size_t)ntiles * RX_TILE;
+    uint16_t* gi = sidx + (size_t)blockIdx.x * (size_t)ntiles * RX_TILE;
+    uint32_t KH[RX_E], KL[RX_E], I[RX_E];                    // key (high, low word) and column of the lane's 16 elements
+
+    for (int row = row_first + blockIdx.x * row_stride; row < n; row += gridDim.x * row_stride) {
+        const int pa = order[row];
+        const double sig = np_sum[pa], rs = seq_sum[pa];
+        const double* __restrict__ crow = C + (int64_t)pa * ldc;
+        for (int t = 0; t < ntiles; t++) {
+            // the lane index is re-read through an opaque statement in every tile and every pass: otherwise the compiler
+            // hoists dozens of lane-dependent addresses out of the loops and spills them (392 bytes of scratch measured)
+            int tid = tid0;
+            asm volatile("" : "+v"(tid));
+            const int base = t * RX_TILE;
+            unsigned long long o_acc = 0ull, a_acc = ~0ull;
+#pragma unroll
+            for (int q = 0; q < RX_E; q++) {
+                // storage order (coalesced); each cell carries its position in the leaf order (= its column label)
+                const int b = base + RX_E * tid + q;
+                const bool real = b < n;
+                const uint64_t k = real ? key_of(similarity(crow[b], sig, rs)) : ~0ull;    // padding sorts last in every pass
+                KH[q] = (uint32_t)(k >> 32); KL[q] = (uint32_t)k;
+                I[q] = real ? (uint32_t)inv[b] : 0xffffu;
+                if (real) { o_acc |= k; a_acc &= k; }
+            }
+            // key bits that differ somewhere in the tile
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { o_acc |= __shfl_xor(o_acc, off, 64); a_acc &= __shfl_xor(a_acc, off, 64); }
+            __syncthreads();                                    // the previous tile / row is done with the LDS
+            if (lane == 0) { s_or[wave] = o_acc; s_and[wave] = a_acc; }
+            __syncthreads();
+            unsigned long long varying;
+            {
+                unsigned long long oo = 0ull, aa = ~0ull;
+#pragma unroll
+                for (int w = 0; w < 16; w++) { oo |= s_or[w]; aa &= s_and[w]; }
+                varying = oo ^ aa;
+            }
+            for (int pass = 0; pass < 20; pass++) {
+                // the word this pass's digit comes from: the column (4 passes), the key's low word (8), its high word (8)
+                const int word = pass < 4 ? 0 : (pass < 12 ? 1 : 2);
+                const int shift = word == 0 ? 4 * pass : (word == 1 ? 4 * (pass - 4) : 4 * (pass - 12));
+                if (word == 0) { if (pass > 0 && ((n - 1) >> shift) == 0) continue; }       // columns are below n
+                else if (((varying >> (4 * (pass - 4))) & 15ull) == 0ull) continue;           // this digit is the same everywhere
+                asm volatile("" : "+v"(tid));
+                // ---- 1. the lane's digit counts; rk = rank of each element among the lane's equal digits
+                unsigned long long c0 = 0ull, c1 = 0ull, rk = 0ull;
+#pragma unroll
+                for (int q = 0; q < RX_E; q++) {
+                    const uint32_t src = word == 0 ? I[q] : (word == 1 ? KL[q] : KH[q]);
+                    const int d = (int)((src >> shift) & 15u);
+                    const int sh = (d & 7) * 8;
+                    const unsigned long long cur = d < 8 ? c0 : c1;
+                    rk |= ((cur >> sh) & 0xffull) << (4 * q);          // < 16: four bits are enough
+                    if (d < 8) c0 += 1ull << sh; else c1 += 1ull << sh;
+                }
+#pragma unroll
+                for (int d = 0; d < 16; d++) cnt[d * RX_T + tid] = (uint16_t)(((d < 8 ? c0 : c1) >> ((d & 7) * 8)) & 0xffull);
+                __syncthreads();
+                // ---- 2. exclusive scan over cnt[] (16 digits x 1024 lanes) in linear order: this lane owns entries 16 tid .. 16 tid + 15
+                {
+                    const uint4 v0 = *reinterpret_cast<const uint4*>(cnt + 16 * tid), v1 = *reinterpret_cast<const uint4*>(cnt + 16 * tid + 8);
+                    const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    uint32_t sum = 0;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) sum += (w[u] & 0xffffu) + (w[u] >> 16);
+                    uint32_t incl = sum;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+                    if (lane == 63) s_wsum[wave] = incl;
+                    __syncthreads();
+                    uint32_t run = incl - sum;
+#pragma unroll
+                    for (int ww = 0; ww < 16; ww++) if (ww < wave) run += s_wsum[ww];
+                    uint32_t o[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const uint32_t e0 = run; run += w[u] & 0xffffu; const uint32_t e1 = run; run += w[u] >> 16; o[u] = e0 | (e1 << 16); }
+                    uint4 o0, o1;
+                    o0.x = o[0]; o0.y = o[1]; o0.z = o[2]; o0.w = o[3]; o1.x = o[4]; o1.y = o[5]; o1.z = o[6]; o1.w = o[7];
+                    *reinterpret_cast<uint4*>(cnt + 16 * tid) = o0; *reinterpret_cast<uint4*>(cnt + 16 * tid + 8) = o1;
+                }
+                __syncthreads();
+                // ---- 3. destinations, then the three components through LDS (stable scatter, 16 consecutive back)
+                uint32_t dst2[RX_E / 2];                        // two 14-bit destinations per register
+#pragma unroll
+                for (int q = 0; q < RX_E; q++) {
+                    const uint32_t src = word == 0 ? I[q] : (word == 1 ? KL[q] : KH[q]);
+                    const int d = (int)((src >> shift) & 15u);
+                    const uint32_t dq = (uint32_t)cnt[d * RX_T + tid] + (uint32_t)((rk >> (4 * q)) & 15ull);
+                    if (q & 1) dst2[q >> 1] |= dq << 16; else dst2[q >> 1] = dq;
+                }
+#define RX_DST(q) ((dst2[(q) >> 1] >> (((q) & 1) * 16)) & 0xffffu)
+#pragma unroll
+                for (int q = 0; q < RX_E; q++) stage[RX_DST(q)] = KH[q];
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < RX_E / 4; u++) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(stage + RX_E * tid + 4 * u);
+                    KH[4 * u] = v.x; KH[4 * u + 1] = v.y; KH[4 * u + 2] = v.z; KH[4 * u + 3] = v.w;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < RX_E; q++) { stage[RX_DST(q)] = KL[q]; stidx[RX_DST(q)] = (uint16_t)I[q]; }
+#undef RX_DST
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < RX_E / 4; u++) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(stage + RX_E * tid + 4 * u);
+                    KL[4 * u] = v.x; KL[4 * u + 1] = v.y; KL[4 * u + 2] = v.z; KL[4 * u + 3] = v.w;
+                }
+                {
+                    const uint4 v0 = *reinterpret_cast<const uint4*>(stidx + RX_E * tid);          // RX_E = 8 columns
+                    const uint32_t w[4] = {v0.x, v0.y, v0.z, v0.w};
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { I[2 * u] = w[u] & 0xffffu; I[2 * u + 1] = w[u] >> 16; }
+                }
+                __syncthreads();
+            }
+            if (ntiles > 1) {
+#pragma unroll
+                for (int q = 0; q < RX_E; q++) { gk[base + RX_E * tid + q] = ((uint64_t)KH[q] << 32) | KL[q]; gi[base + RX_E * tid + q] = (uint16_t)I[q]; }
+            }
+        }
+        __syncthreads();                                        // the image aliases the pass buffers
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        if (ntiles == 1) {
+#pragma unroll
+            for (int q = 0; q < RX_E; q++) { const int pos = RX_E * tid + q; if (pos < n) image[I[q]] = (uint16_t)(n - 1 - pos); }
+        } else {
+            __threadfence_block();
+            for (int t = 0; t < ntiles; t++) {
+                asm volatile("" : "+v"(tid));
+                const int base = t * RX_TILE, len = n - base < RX_TILE ? n - base : RX_TILE;
+                if (RX_E * tid >= len) continue;
+                uint32_t lb[RX_E];                               // sum over the other tiles of the element's lower bound there
+#pragma unroll
+                for (int q = 0; q < RX_E; q++) lb[q] = 0;
+                for (int o = 0; o < ntiles; o++) {
+                    if (o == t) continue;
+                    const uint64_t* __restrict__ ok = gk + o * RX_TILE;
+                    const uint16_t* __restrict__ oi = gi + o * RX_TILE;
+                    const int olen = n - o * RX_TILE < RX_TILE ? n - o * RX_TILE : RX_TILE;
+                    const uint64_t k0 = gk[base + RX_E * tid];
+                    const uint32_t i0 = gi[base + RX_E * tid];
+                    int lo = 0, hi2 = olen;                      // lower bound of the lane's first element in tile o
+                    while (lo < hi2) {
+                        const int mid = (lo + hi2) >> 1;
+                        if (rx_less(ok[mid], oi[mid], k0, i0)) lo = mid + 1; else hi2 = mid;
+                    }
+                    // the other elements: walk forward (consecutive elements have neighbouring bounds).  (key, column)
+                    // pairs are all different, so "strictly less" counts exactly the elements that come before ours
+#pragma unroll
+                    for (int q = 0; q < RX_E; q++) {
+                        if (q > 0 && RX_E * tid + q < len) {
+                            const uint64_t kq = gk[base + RX_E * tid + q];
+                            const uint32_t iq = gi[base + RX_E * tid + q];
+                            while (lo < olen && rx_less(ok[lo], oi[lo], kq, iq)) lo++;
+                        }
+                        lb[q] += (uint32_t)lo;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < RX_E; q++)
+                    if (RX_E * tid + q < len) image[gi[base + RX_E * tid + q]] = (uint16_t)(n - 1 - (RX_E * tid + q) - (int)lb[q]);
+            }
+        }
+        __syncthreads();
+        uint16_t* __restrict__ out = rank + (int64_t)row * ldr;
+        for (int e = tid * 8; e < n; e += RX_T * 8) *reinterpret_cast<uint4*>(out + e) = *reinterpret_cast<const uint4*>(image + e);
+        __syncthreads();
+    }
+}
+
+static constexpr int RX_MAXWG = 512;
+size_t sort_radix_scratch_bytes(int n)
+{
+    const size_t ntiles = ((size_t)n + RX_TILE - 1) / RX_TILE;
+    return ntiles > 1 ? (size_t)RX_MAXWG * ntiles * RX_TILE * (sizeof(uint64_t) + sizeof(uint16_t)) : 16;
+}
+
+// rank[row][col] = position of col in row's descending order, for this shard's rows (no argsort rows, no inversion pass)
+void launch_rank_rows_radix(const double* C, int64_t ldc, const int32_t* order, const int32_t* inv, const double* np_sum,
+                            const double* seq_sum, int n, void* scratch, uint16_t* rank, int64_t ldr, int row_first,
+                            int row_stride, hipStream_t s)
+{
+    const int ntiles = (n + RX_TILE - 1) / RX_TILE;
+    const int mine = n > row_first ? (n - row_first + row_stride - 1) / row_stride : 0;
+    if (mine <= 0) return;
+    // LDS: the pass buffers (80 KB), or the row's rank image if that is larger (2 bytes per column)
+    const size_t image = (((size_t)n * 2) + 15) & ~(size_t)15;
+    const size_t lds = image > RX_LDS ? image : RX_LDS;
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int wgs = mine < 256 * per_cu ? mine : 256 * per_cu;
+    uint64_t* skeys = reinterpret_cast<uint64_t*>(scratch);
+    uint16_t* sidx = reinterpret_cast<uint16_t*>(skeys + (size_t)RX_MAXWG * (size_t)ntiles * RX_TILE);
+    static std::atomic<int> have{0};
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_sort_rows_radix), have, lds);
+    hipLaunchKernelGGL(k_sort_rows_radix, dim3(wgs), dim3(RX_T), lds, s, C, ldc, order, np_sum, seq_sum, n, skeys, sidx, rank, ldr,
+                       inv, row_first, row_stride);
+}
+
 void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const int32_t* inv, const double* np_sum,
                       const double* seq_sum, int n, void* scratch, uint16_t* R, int64_t ldr, int row_first, int row_stride,
                       hipStream_t s)

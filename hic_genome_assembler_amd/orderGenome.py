@@ -845,14 +845,20 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, chromosomeGroup
 
 
 def runResident(adjMat: GenomeMatrix, binList, chromosomeGroupFile, chromosomeOrderFile, plotOrderFile,
-                nScaffolds, scanScaffolds, resolution, savePlotDir=False, plotTitleSuffix=False, shard=None):
+                nScaffolds, scanScaffolds, resolution, savePlotDir=False, plotTitleSuffix=False, shard=None,
+                chromosomeList=None):
     """OG:691-709 on contacts that are already resident in HBM (what bench.py times).  ``binList``
     gives the bin of every row of the device matrix; bins that Part 1 did not assign to a group are
     simply never selected, which is what the reference's re-load restricted to grouped bins
     (OG:688-690) amounts to.  ``shard=(rank, world)``: see ``orderGenome``; every rank returns the whole order
-    and rank 0 writes the two files."""
+    and rank 0 writes the two files.  ``chromosomeList``: the groups as readChromsFromFile would return them for
+    chromosomeGroupFile (Part 1's ``DeviceMatrix.chromosome_groups``) when that file is still being written."""
     with paused_gc():
-        chromosomeList = readChromsFromFile(chromosomeGroupFile)
+        if chromosomeList is None:
+            chromosomeList = readChromsFromFile(chromosomeGroupFile)
+        else:
+            print("Chromosomes found " + str(len(chromosomeList)))
+            print("Nodes found " + str(sum(len(c) for c in chromosomeList)))
         orderedChromosomes = orderGenome(adjMat, chromosomeList, binList, resolution, nScaffolds=nScaffolds,
                                          scanScaffolds=scanScaffolds, plotChrom=True, showPlot=False,
                                          savePlotDir=savePlotDir, plotTitleSuffix=plotTitleSuffix, shard=shard)

@@ -388,8 +388,14 @@ def assessClusterList(cList, scaffDict, outFile, percentToAssign=51.):
     return res
 
 
-def assessChromosomeClustering(chromList, statsFile, percentToAssign=51.):
-    """S2C:1038-1077.  ``chromList``: groups of bin-grouping lines (``ID<TAB>scaffold<TAB>...``)."""
+def _write_text(path, text):
+    with open(path, "w") as fh:
+        fh.write(text)
+
+
+def assessChromosomeClustering(chromList, statsFile, percentToAssign=51., write=None):
+    """S2C:1038-1077.  ``chromList``: groups of bin-grouping lines (``ID<TAB>scaffold<TAB>...``).  ``write``: called as
+    ``write(fn, *args)`` to put the report on disk (default: at once)."""
     groups = [_pairs_of_lines(grp) for grp in chromList]
     scaffolds = {}
     for grp in groups:
@@ -412,19 +418,27 @@ def assessChromosomeClustering(chromList, statsFile, percentToAssign=51.):
     out.append("Falsely clustered nodes " + str(false_pos) + "\n")
     out.append("Total scaffolds assigned to chromosomes " + str(assigned) + "\n")
     out.append("Error rate ~" + str(round((float(false_pos) / float(total)) * 100., 2)) + "%\n")
-    with open(statsFile, "w") as fh:
-        fh.write("".join(out))
+    if write is None:
+        _write_text(statsFile, "".join(out))
+    else:
+        write(_write_text, statsFile, "".join(out))
     return final
+
+
+def rankChromosomeGroups(chromList, scaffSizeDict):
+    """The order in which S2C:1079-1100 writes the groups: by total scaffold bp, largest first (stable).  What
+    orderGenome.readChromsFromFile gives back for the file written from it."""
+    sizes = [sum(scaffSizeDict[s] for s in {e[1]: '' for e in grp}) for grp in chromList]
+    ranked = sorted(range(len(chromList)), key=lambda k: sizes[k], reverse=True)
+    return [chromList[k] for k in ranked]
 
 
 def writeChromosomeGroupingsToFile(chromList, scaffSizeDict, outFile):
     """S2C:1079-1100: groups ordered by total scaffold bp, largest first (stable)."""
-    sizes = [sum(scaffSizeDict[s] for s in {e[1]: '' for e in grp}) for grp in chromList]
-    ranked = sorted(range(len(chromList)), key=lambda k: sizes[k], reverse=True)
     text = []
-    for new_id, k in enumerate(ranked):
+    for new_id, grp in enumerate(rankChromosomeGroups(chromList, scaffSizeDict)):
         text.append("### Chromosome group " + str(new_id + 1) + " ###\n")
-        text.extend(str(e[0]) + "\t" + str(e[1]) + "\n" for e in chromList[k])
+        text.extend(str(e[0]) + "\t" + str(e[1]) + "\n" for e in grp)
     with open(outFile, "w") as fh:
         fh.write("".join(text))
 
@@ -470,11 +484,43 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, hicProScaffSize
     return (adjMat, adjMat.kept_bins) if keep_resident else None
 
 
+class _FileWriter:
+    """Part 1's text files written on one background thread while the device (and then Part 2) keeps working: the
+    strings are built and written in submission order; ``finish()`` returns when every file is on disk and re-raises
+    what a writer raised."""
+
+    def __init__(self, enabled):
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=1) if enabled else None
+        self.jobs = []
+
+    def submit(self, fn, *args):
+        if self.pool is None:
+            return fn(*args)
+        self.jobs.append(self.pool.submit(fn, *args))
+
+    def finish(self):
+        for j in self.jobs:
+            j.result()
+        self.jobs = []
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
+            self.pool = None
+
+
 def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOrderFile, binGroupFile,
-                assessmentFile, chromosomeGroupFile, minSize, modularity, psig, louvainRounds=20, shard=None):
+                assessmentFile, chromosomeGroupFile, minSize, modularity, psig, louvainRounds=20, shard=None,
+                overlap_files=False):
     """S2C:1117-1167 on a contact map that is already resident in HBM (what bench.py times): every
     stage after the text loaders, including the small intermediate files the reference round-trips
-    through.  Returns the filtered cut indices; ``binList`` is left in .bed order for the caller."""
+    through.  Returns the filtered cut indices; ``binList`` is left in .bed order for the caller.
+
+    ``overlap_files=True``: the four files are written by a background thread (the dendrogram order while the rows
+    are sorted and scanned, the three group files while the caller goes on); the caller hands
+    ``adjMat.chromosome_groups`` - what Part 2 would read back from chromosomeGroupFile - to
+    ``orderGenome.runResident(..., chromosomeList=)`` and calls ``adjMat.finish_files()`` before it uses the files."""
+    writer = _FileWriter(overlap_files)
+    adjMat.finish_files = writer.finish
     with paused_gc():
         t0 = time.time()
         if shard is not None:
@@ -487,7 +533,7 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
         adjMat = convertMatrix(adjMat, binList, distance=True, similarity=False)
         dendroLabels = [b.chrom + '_' + str(b.ID) for b in binList]
         dendrogram = averageClusterNodes(adjMat, dendroLabels, noPlot=True)
-        dendrogramLeafOrder_toFile(dendrogram, dendrogramOrderFile)
+        writer.submit(dendrogramLeafOrder_toFile, dendrogram, dendrogramOrderFile)
         # the reference parses the file back (readDengrogramLeavesFromFile); the leaves are the same integers
         adjMat, binList = reorderMatrix(adjMat, binList, dendrogram['leaves'])
         print("Total run-time to cluster = " + str(time.time() - t0))
@@ -507,13 +553,16 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
                 new_order, cutIndices = louvain.modularity_remaining_data(louvain.log_transform(sim_tail), binList,
                                                                           cutIndices, n_rounds=louvainRounds)
                 adjMat, binList = reorderMatrix(adjMat, binList, new_order)
-        writeBinGroupingsToFile(cutIndices, binList, binGroupFile)
+        writer.submit(writeBinGroupingsToFile, list(cutIndices), list(binList), binGroupFile)
         binGroups = _bin_group_pairs(cutIndices, binList)
         print("Total run-time to identify chromosome boundaries = " + str(time.time() - t0))
         t0 = time.time()
         fastaSizeDict = readSizeFileToDict(hicProScaffSizeFile)
         print(str(len(binGroups)) + " chromosomes read in from file")      # == readBinGroupingsFromFile(binGroupFile)
-        chrGroups = assessChromosomeClustering(binGroups, assessmentFile)
-        writeChromosomeGroupingsToFile(chrGroups, fastaSizeDict, chromosomeGroupFile)
+        chrGroups = assessChromosomeClustering(binGroups, assessmentFile, write=writer.submit)
+        adjMat.chromosome_groups = rankChromosomeGroups(chrGroups, fastaSizeDict)
+        writer.submit(writeChromosomeGroupingsToFile, chrGroups, fastaSizeDict, chromosomeGroupFile)
         print("Total run-time to assign scaffolds to chromosomes = " + str(time.time() - t0))
+    if not overlap_files:
+        writer.finish()
     return cutIndices

@@ -166,6 +166,17 @@ def dense_contacts_torch(layout: Layout, device, seed: int = 1, sigma: float = 0
     return c
 
 
+def sparsify(contacts: np.ndarray, zero_fraction: float, decimals: int) -> np.ndarray:
+    """What real HiC-Pro maps look like and the dense maps above do not: values rounded to ``decimals`` places (exact
+    duplicates everywhere) and the smallest ``zero_fraction`` of the cells set to exactly 0 (similarity exactly 0,
+    distance exactly 2.0: long runs of ties in every row).  The diagonal keeps at least 1.0 so no row empties."""
+    c = np.round(contacts, decimals)
+    c[c <= np.quantile(c, zero_fraction)] = 0.0
+    c = 0.5 * (c + c.T)
+    np.fill_diagonal(c, np.maximum(np.diag(c), 1.0))
+    return np.ascontiguousarray(c)
+
+
 def write_hicpro(out_dir: str, layout: Layout, contacts: np.ndarray, prefix: str = "synth",
                  nan_bias_bins=()) -> dict:
     """Write ``.bed``, ``.biases``, ``.matrix`` (upper-triangle triplets) and the scaffold size file.

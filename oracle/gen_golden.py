@@ -45,6 +45,15 @@ CASES = {
                  n_scaffolds=4, scan_scaffolds=3, store_matrices=False),
     "n2000": dict(n=2000, seed=2, n_chrom=8, mean_scaffold_bins=13.0, min_size=5, psig=0.05,
                   n_scaffolds=4, scan_scaffolds=3, store_matrices=False),
+    # what real HiC-Pro maps look like: 2-decimal values, 45 % exact zeros - ties in the clustering (SciPy's nn_chain
+    # tie rule) and in every row of the argsort (NumPy's unstable sort: tie order undefined)
+    "n500_sparse": dict(n=500, seed=11, n_chrom=4, mean_scaffold_bins=8.0, min_size=5, psig=0.05,
+                        n_scaffolds=4, scan_scaffolds=3, sparse=(0.45, 2), store_matrices=False),
+    # the cost loop as Numba compiles it: numpy.trace inside a nopython function is a sequential loop (numba's
+    # np_trace), not NumPy's pairwise add.reduce - the shim patches orderGenome.numpyTrace (the name the jitted
+    # function calls, OG:8,188) with that loop; the totals (OG:343,448,506) stay NumPy's
+    "n160_numba": dict(n=160, seed=3, n_chrom=4, mean_scaffold_bins=6.0, min_size=5, psig=0.05,
+                       n_scaffolds=4, scan_scaffolds=3, numba_trace="sequential", store_matrices=False),
 }
 
 OUTPUT_FILES = ["dendrogramOrder.txt", "binGroups.txt", "assessment.txt", "chromosomeGroups.txt",
@@ -59,6 +68,8 @@ def build_case(name, spec, work):
     lay = synth.make_layout(spec["n"], seed=spec["seed"], n_chrom=spec["n_chrom"],
                             mean_scaffold_bins=spec["mean_scaffold_bins"])
     c = synth.dense_contacts(lay, seed=spec["seed"])
+    if spec.get("sparse"):
+        c = synth.sparsify(c, *spec["sparse"])
     for b in spec.get("zero_bins", ()):            # bins without any contact: dropped by removeRows
         c[b, :] = 0.0
         c[:, b] = 0.0
@@ -74,6 +85,16 @@ def build_case(name, spec, work):
 def run_reference(spec, paths, out_dir, plot_dir):
     s2c, og = ref_shim.load()
     rec = {"hyper": [], "costs": [], "chrom_orders": []}
+    numpy_trace = og.numpyTrace
+    if spec.get("numba_trace") == "sequential":
+        def sequential_trace(a, offset=0):        # numba/np/arraymath.py np_trace: ret = 0; for i in range(n): ret += a[i, k + i]
+            rows, cols = a.shape
+            n = max(min(rows, cols - offset), 0)
+            ret = 0
+            for i in range(n):
+                ret += a[i, offset + i]
+            return ret
+        og.numpyTrace = sequential_trace
 
     # ---- passive recorders (call through, copy results) ----
     orig = {}
@@ -158,6 +179,7 @@ def run_reference(spec, paths, out_dir, plot_dir):
     finally:
         for (mod, fname), fn in orig.items():
             setattr(mod, fname, fn)
+        og.numpyTrace = numpy_trace
     rec["seconds_part1"] = t1 - t0
     rec["seconds_part2"] = t2 - t1
     return rec

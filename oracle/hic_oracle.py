@@ -58,11 +58,19 @@ def lib():
         L.hio_total_upper.argtypes = [dp, ctypes.c_long, ip, ctypes.c_long]
         L.hio_cost_literal.restype = ctypes.c_double
         L.hio_cost_literal.argtypes = [dp, ctypes.c_long, ip, ctypes.c_long, ctypes.c_double]
+        L.hio_set_trace_order.restype = None
+        L.hio_set_trace_order.argtypes = [ctypes.c_int]
         L.hio_cost_literal_batch.restype = None
         L.hio_cost_literal_batch.argtypes = [dp, ctypes.c_long, ip, ctypes.c_long, ctypes.c_long,
                                              ctypes.c_double, dp]
         _LIB = L
     return _LIB
+
+
+def set_trace_order(order: str):
+    """"numpy" (default): numpy.trace's pairwise sums in the cost loop; "numba": the sequential loop Numba compiles for
+    numpy.trace inside costFunction_numba (orderGenome.py:184-191).  The totals (OG:343,448,506) are NumPy's either way."""
+    lib().hio_set_trace_order(1 if order == "numba" else 0)
 
 
 def _dp(a):

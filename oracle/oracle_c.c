@@ -214,6 +214,20 @@ static double diag_sum_perm(const double *M, long ld, const int32_t *perm, long 
     return hio_np_sum(scratch, len, 1);
 }
 
+/* numpy.trace as NUMBA compiles it inside costFunction_numba (orderGenome.py:184-191, nopython mode):       */
+/* numba's np_trace is `ret = 0; for i in range(n): ret += a[i, k + i]` - sequential, not pairwise.  Selected */
+/* with hio_set_trace_order(1) for the cost functions only; the totals stay NumPy's (orderGenome.py:343).    */
+static int g_sequential_trace = 0;
+void hio_set_trace_order(int sequential) { g_sequential_trace = sequential; }
+
+static double diag_sum_cost(const double *M, long ld, const int32_t *perm, long n, long off, double *scratch)
+{
+    if (!g_sequential_trace) return diag_sum_perm(M, ld, perm, n, off, scratch);
+    double acc = 0.0;
+    for (long a = 0; a < n - off; a++) acc += M[(long)perm[a] * ld + perm[a + off]];
+    return acc;
+}
+
 double hio_total_upper(const double *M, long ld, const int32_t *perm, long n)
 {
     /* Python sum() of the per-offset traces, offsets 1..n-1 (orderGenome.py:343,448,506) */
@@ -229,7 +243,7 @@ double hio_cost_literal(const double *M, long ld, const int32_t *perm, long n, d
     double *scratch = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
     double cum = 0.0, cost = 0.0;
     for (long off = 1; off < n; off++) {
-        cum += diag_sum_perm(M, ld, perm, n, off, scratch);
+        cum += diag_sum_cost(M, ld, perm, n, off, scratch);
         cost += (cum / total / (double)off);
     }
     free(scratch);

@@ -33,6 +33,8 @@ def load_case(name):
     lay = synth.make_layout(spec["n"], seed=spec["seed"], n_chrom=spec["n_chrom"],
                             mean_scaffold_bins=spec["mean_scaffold_bins"])
     c = synth.dense_contacts(lay, seed=spec["seed"])
+    if spec.get("sparse"):
+        c = synth.sparsify(c, *spec["sparse"])
     for b in spec.get("zero_bins", ()):
         c[b, :] = 0.0
         c[:, b] = 0.0

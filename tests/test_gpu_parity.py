@@ -13,7 +13,9 @@ import golden_cases as gc
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["n160", "n300_edges", "n400_default", "n600", "n2000"]
+CASES = ["n160", "n300_edges", "n400_default", "n600", "n2000", "n500_sparse", "n160_numba"]
+# n500_sparse: 2-decimal contacts with 50 % exact zeros (ties in the clustering and in every sorted row);
+# n160_numba: the reference's cost loop with numpy.trace summed as Numba compiles it (HICMI_P2_TRACE_ORDER=numba)
 
 
 @pytest.fixture(scope="module")
@@ -459,6 +461,37 @@ def test_p2_literal_scores_bit_exact(hic, orc, n_used):
     assert np.allclose(fast, exact, rtol=1e-11, atol=0)
 
 
+@pytest.mark.parametrize("n_used", [2, 9, 130, 1000, 1100])
+def test_p2_literal_scores_in_numba_order_bit_exact(hic, orc, monkeypatch, n_used):
+    """HICMI_P2_TRACE_ORDER=numba: the candidates' diagonal sums run left to right (what Numba's np_trace does inside
+    costFunction_numba, orderGenome.py:184-191) while the total keeps NumPy's pairwise order - bit for bit against the
+    oracle's restatement of that loop, and different from the NumPy order in the last bits."""
+    rng = np.random.default_rng(n_used)
+    n = n_used + 5
+    m = rng.random((n, n)) * 7.0; m = m + m.T
+    sel = rng.permutation(n)[:n_used].astype(np.int32)
+    perms = np.stack([rng.permutation(n_used) for _ in range(5)]).astype(np.int32)
+    L = orc.lib()
+    sub = np.ascontiguousarray(m[np.ix_(sel, sel)])
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(m)
+        ctx.p2_select(sel)
+        total = ctx.p2_total()
+        numpy_order = ctx.p2_score_exact(perms, total)
+        monkeypatch.setenv("HICMI_P2_TRACE_ORDER", "numba")
+        assert ctx.p2_total() == total                              # the total is not part of the jitted function
+        numba_order = ctx.p2_score_exact(perms, total)
+    orc.set_trace_order("numba")
+    try:
+        want = [L.hio_cost_literal(orc._dp(sub), n_used, orc._ip(perms[k]), n_used, total) for k in range(len(perms))]
+    finally:
+        orc.set_trace_order("numpy")
+    assert numba_order.tolist() == want
+    assert np.allclose(numba_order, numpy_order, rtol=1e-13, atol=0)
+    if n_used == 130:                                               # (long rows: the last bits of a diagonal vanish in `cum`)
+        assert np.any(numba_order != numpy_order)
+
+
 def test_p2_device_enumeration_matches_explicit_candidates(hic, orc):
     """Insertion and window candidates enumerated by the kernels (k_part2_search.hip) against the
     same candidates spelled out as index lists and scored by hicmi_p2_score / the oracle."""
@@ -529,12 +562,20 @@ def _run_product(name, tmp_path, record=None):
                    True, False, spec["min_size"], 0.0, 20, spec["psig"], 5, .2, 100000)
     if record is not None:
         p2.SCORE_HOOK = lambda fast: record.extend(float(v) for v in fast)
+    before = os.environ.get("HICMI_P2_TRACE_ORDER")
+    if spec.get("numba_trace"):
+        os.environ["HICMI_P2_TRACE_ORDER"] = "numba"
     try:
         p2.runPipeline(paths["hicProBedFile"], paths["hicProBiasFile"], paths["hicProMatrixFile"],
                        f("chromosomeGroups.txt"), f("chromosomeOrders.txt"), out, "synthetic", f("g.png"),
                        "synthetic genome", f("plotOrder.txt"), spec["n_scaffolds"], spec["scan_scaffolds"], 100000)
     finally:
         p2.SCORE_HOOK = None
+        if spec.get("numba_trace"):
+            if before is None:
+                del os.environ["HICMI_P2_TRACE_ORDER"]
+            else:
+                os.environ["HICMI_P2_TRACE_ORDER"] = before
     return out
 
 
@@ -846,11 +887,15 @@ def test_fp32_contacts_are_widened_exactly(hic):
                 assert np.array_equal(z32, z64) and np.array_equal(l32, l64)
 
 
-def test_row_sort_across_tiles_with_ties(hic):
-    """Rows longer than the 16384-element tile are sorted tile by tile and merged through the scratch buffer; with
-    quantised contacts (heavy ties) the order must still be "stable ascending, reversed" of the similarity row."""
+@pytest.mark.parametrize("n,sorter", [(16500, "radix"), (16500, "bitonic"), (8193, "radix"), (64000, "radix")])
+def test_row_sort_across_tiles_with_ties(hic, monkeypatch, n, sorter):
+    """Rows longer than one tile (8192 elements for the LSD radix kernel, 16384 for the bitonic networks) are sorted
+    tile by tile and combined - by lower bounds in the other tiles / by merge levels through the scratch buffer; with
+    quantised contacts (heavy ties) the order must still be "stable ascending, reversed" of the similarity row.
+    64,000 columns: the row length of BASELINE configs[4]."""
     import torch
-    n = 16500
+    if sorter == "bitonic":
+        monkeypatch.setenv("HICMI_SORT_BITONIC", "1")
     g = torch.Generator(device="cuda:0")
     g.manual_seed(5)
     c = torch.randint(0, 40, (n, n), generator=g, device="cuda:0").to(torch.float64)
@@ -867,4 +912,6 @@ def test_row_sort_across_tiles_with_ties(hic):
             want = np.argsort(sim, kind="stable")[::-1]
             got = ctx.rank_rows(r, 1)[0].astype(np.int64)
             assert np.array_equal(got, want), r
+            inv = ctx.rank_rows(r, 1, inverse=True)[0].astype(np.int64)
+            assert np.array_equal(inv[want], np.arange(n)), r
             assert len(np.unique(sim)) < n // 10                               # the ties are really there

@@ -11,7 +11,7 @@ import golden_cases as gc
 import hic_oracle as orc
 
 FAST_CASES = ["n160", "n300_edges", "n600"]
-ALL_CASES = FAST_CASES + ["n400_default", "n2000"]
+ALL_CASES = FAST_CASES + ["n400_default", "n2000", "n500_sparse", "n160_numba"]
 
 
 # ---------------------------------------------------------------- known answers held by the reference
@@ -108,8 +108,16 @@ def _run_oracle(name, tmp_path):
 
 @pytest.mark.parametrize("name", ALL_CASES)
 def test_oracle_reproduces_reference_outputs(name, tmp_path):
+    """n500_sparse: 2-decimal values and 50 % exact zeros, i.e. ties in SciPy's nn_chain and in every row of NumPy's
+    (unstable) argsort - on THIS fixture the build's tie rules give the reference's files, linkage and cuts (tie order
+    is implementation-defined in NumPy: parity is pinned for this container's NumPy 2.2.6 only).
+    n160_numba: the cost loop summed as Numba compiles numpy.trace (sequential), selected with set_trace_order."""
     spec, meta, gold, lay, c = gc.load_case(name)
-    t1, t2, out = _run_oracle(name, tmp_path)
+    orc.set_trace_order("numba" if spec.get("numba_trace") else "numpy")
+    try:
+        t1, t2, out = _run_oracle(name, tmp_path)
+    finally:
+        orc.set_trace_order("numpy")
     # integer / byte outputs: exact
     for fn in gc.OUTPUT_FILES:
         with open(os.path.join(out, fn)) as fh:
@@ -123,13 +131,28 @@ def test_oracle_reproduces_reference_outputs(name, tmp_path):
     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
     assert sha(t1["dist_reordered"]) != ""   # (reordered distance is not a recorded stage)
     assert sha(t1["sim"]) == meta["sha256"]["S"]
-    assert sha(t1["R"].astype(np.int64)) == meta["sha256"]["argsorted"]
+    if not spec.get("sparse"):                                  # with ties NumPy's unstable order differs inside the runs
+        assert sha(t1["R"].astype(np.int64)) == meta["sha256"]["argsorted"]
+    else:
+        assert np.array_equal(t1["R"][:, :8], gold["argsorted_head"])
+        assert np.count_nonzero(c == 0) > 0.4 * c.size and len(np.unique(c)) < c.size // 20
     # every hypergeometric evaluation of the first pass, in call order
     k0, k1 = int(gold["hyper_mark_first_pass"]), int(gold["hyper_mark_filter"])
     ref_x = gold["hyper_xMnN"][k0:k1]
     mine = np.concatenate([np.stack([e["x"], np.full(len(e["x"]), e["M"]), np.arange(1, len(e["x"]) + 1),
                                      np.arange(1, len(e["x"]) + 1)], axis=1) for e in t1["first_pass"]]) \
         if t1["first_pass"] else np.zeros((0, 4), np.int64)
+    if spec.get("sparse"):
+        # NumPy's unstable argsort orders a run of equal similarities differently from the build's rule (stable
+        # ascending, reversed), so a count whose prefix ends INSIDE a run of ties can differ: the arguments (M, n, N)
+        # agree everywhere, 43 % of the x do not - "parity unpinned" for tie order.  On this fixture every
+        # decision downstream (cut lists, files: asserted above) still coincides, although single counts differ by up
+        # to a hundred: that is luck of this map, not a property - on real (sparse) maps cut indices may differ from
+        # a reference run, just as two NumPy builds may differ from each other.
+        assert np.array_equal(mine[:, 1:], ref_x[:len(mine), 1:])
+        differ = mine[:, 0] != ref_x[:len(mine), 0]
+        assert 0.2 < np.mean(differ) < 0.7
+        return
     assert np.array_equal(mine, ref_x[:len(mine)])
     # what is left are the futile window-shrinking retries of the LAST call (S2C:499-508): the
     # same rows scanned again min_size-1 times; they cannot produce a cut (see hic_oracle docstring)
@@ -141,3 +164,16 @@ def test_oracle_reproduces_reference_outputs(name, tmp_path):
     # Part 2 objective values in the reference's evaluation order: fp64, same summation -> exact
     assert len(t2["costs"]) == len(gold["costs"])
     assert np.array_equal(t2["costs"], gold["costs"])
+
+
+def test_numba_trace_order_differs_in_the_last_bits_only():
+    """The two fixtures of the same 160-bin map: NumPy's pairwise trace vs Numba's sequential loop in the cost
+    function - 1,712 objective values, some 40 % of them different in the last bits, none by more than 1e-15
+    relative, and (on this map) the same six files."""
+    g1, g2 = gc.load_case("n160")[2], gc.load_case("n160_numba")[2]
+    a, b = g1["costs"], g2["costs"]
+    assert len(a) == len(b) == 1712
+    assert 0.2 < np.mean(a != b) < 0.8
+    assert np.max(np.abs(a - b) / np.abs(a)) < 2e-15
+    for fn in gc.OUTPUT_FILES:
+        assert gc.golden_text("n160", fn) == gc.golden_text("n160_numba", fn)
