@@ -202,7 +202,8 @@ class Job:
             if not a.part1_only:
                 p2.runResident(p2.GenomeMatrix(self.ctx), dm.kept_bins, f("chromosomeGroups.txt"),
                                f("chromosomeOrders.txt"), f("plotOrder.txt"), a.n_scaffolds, a.scan_scaffolds,
-                               self.lay.resolution, shard=self.shard, chromosomeList=dm.chromosome_groups)
+                               self.lay.resolution, shard=self.shard, chromosomeList=dm.chromosome_groups,
+                               on_native_phase=dm.release_files)
             dm.finish_files()
         self.last["part2_s"] = time.perf_counter() - ta - self.last["part1_s"]
         self.last["cuts"] = cuts

@@ -657,9 +657,12 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
     int rc = compute_sums(c);
     if (rc) return rc;
     const int64_t ldr = (n + 63) & ~(int64_t)63;
-    // HICMI_SORT_BITONIC=1 (or HICMI_SORT_LDS=1): the earlier bitonic networks, which produce the argsort rows R and need
-    // the inversion pass; the default LSD radix kernel writes the rank rows directly
-    const bool bitonic = getenv("HICMI_SORT_BITONIC") != nullptr || getenv("HICMI_SORT_LDS") != nullptr;
+    // Default: the register-blocked bitonic network (argsort rows R, then the inversion pass).  HICMI_SORT_RADIX=1: the LSD
+    // radix kernel, which writes the rank rows directly - built to get rid of the O(n log^2 n) stages and of the scratch
+    // round trips of long rows, verified against the same tests, and measured SLOWER on MI355X (16k / 32k / 64k bins:
+    // 15.7 / 87 / 581 ms against 11.7 / 50.6 / 236 ms): 18 passes x 7 workgroup barriers and random 4-byte LDS scatters
+    // cost more than the 105 register-resident stages.  Kept as the second implementation the large-map tests compare with.
+    const bool bitonic = getenv("HICMI_SORT_RADIX") == nullptr;
     if (c->r_rows < n || c->ldr != ldr || !c->dRank) {
         free_dev(c->dR); free_dev(c->dRank); free_dev(c->d_order); c->dR = c->dRank = nullptr; c->d_order = nullptr;
         HIPCHK(hipMalloc((void**)&c->dRank, sizeof(uint16_t) * (size_t)n * (size_t)ldr));

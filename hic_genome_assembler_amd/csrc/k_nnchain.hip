@@ -593,15 +593,13 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_nc(double* __restrict__
             if (PROFILE && tid == 0) { t1 = wall_clock64(); t_book += t1 - t0; t0 = t1; }
             const int tx = s_tx;
             const double* __restrict__ rowx = W + (int64_t)x * ld;
-            if (tid == 64 && prev >= 0 && ((smask[prev >> 5] >> (prev & 31)) & 1u)) s_dprev = rowx[prev];
-            ArgMinT cand = {__builtin_inf(), 0x7fffffff, 0};
+            // gathered values are loaded here and used after the streaming loop (see the update below)
+            const bool want_dp = tid == 64 && prev >= 0 && ((smask[prev >> 5] >> (prev & 31)) & 1u);
+            double dpv = 0.0, cv = 0.0; int cd = -1;
+            if (want_dp) dpv = rowx[prev];
             if (tid < D) {
                 const int d = dslot[tid];
-                if (d >= 0 && d != x && ((alive[d >> 5] >> (d & 31)) & 1u)) {
-                    const double v = dtime[tid] > tx ? W[(int64_t)d * ld + x] : rowx[d];
-                    cand.v = v; cand.i = d;
-                    if (d == prev) s_dprev = v;
-                }
+                if (d >= 0 && d != x && ((alive[d >> 5] >> (d & 31)) & 1u)) { cv = dtime[tid] > tx ? W[(int64_t)d * ld + x] : rowx[d]; cd = d; }
             }
             ArgMinT best = {__builtin_inf(), 0x7fffffff, 0};
 #pragma unroll 8
@@ -611,14 +609,15 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_nc(double* __restrict__
                 if ((bits & 1u) && v.x <= best.v) { if (v.x < best.v) { best.v = v.x; best.i = j; best.t = 0; } else best.t = 1; }
                 if ((bits & 2u) && v.y <= best.v) { if (v.y < best.v) { best.v = v.y; best.i = j + 1; best.t = 0; } else best.t = 1; }
             }
-            if (cand.i != 0x7fffffff) best = argmint_join(best, cand.v, cand.i, 0);
-            best = argmint_wave(best);
+            if (want_dp) s_dprev = dpv;
+            if (cd >= 0) { best = argmint_join(best, cv, cd, 0); if (cd == prev) s_dprev = cv; }
+            best = argmint_wave_fast(best);
             if (lane == 0) { s_v[wave] = best.v; s_i[wave] = best.i; s_t[wave] = best.t; }
             __syncthreads();
             if (PROFILE && tid == 0) { t1 = wall_clock64(); t_scan += t1 - t0; t0 = t1; }
             if (wave == 0) {
                 ArgMinT m = {lane < 16 ? s_v[lane] : __builtin_inf(), lane < 16 ? s_i[lane] : 0x7fffffff, lane < 16 ? s_t[lane] : 0};
-                m = argmint_row16(m);                               // the 16 wave results sit in row 0
+                m = argmint_row16_fast(m);                               // the 16 wave results sit in row 0
                 if (lane == 0) {
                     smask[x >> 5] |= xbit;                          // un-mask the row's own column
                     if (m.i < 0 || m.i >= n) { s_stop = NN_STOP_GUARD; stop_code = NN_STOP_GUARD; }   // NaN distances: nothing compares
@@ -677,27 +676,22 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_nc(double* __restrict__
             const double rcp = 1.0 / fs;
             const double* __restrict__ rx = W + (int64_t)mx * ld;
             double* __restrict__ ry = W + (int64_t)my * ld;
+            // Every gathered value is LOADED here and USED after the streaming pass: a use in front of the loop (a store of
+            // the height, a compare of a dirty partner's new distance) makes its wave wait for the gather before it even
+            // issues its streaming loads - one more memory round trip on the critical path of every merge.
             // the merge height d(x, y): the row of whichever cluster merged last is the authoritative one (column mx of
             // row my is not rewritten below: mx is dead)
-            if (tid == NN_THREADS - 1) zraw[4 * (int64_t)step + 2] = tmx > tmy ? rx[my] : ry[mx];
+            double height = 0.0;
+            if (tid == NN_THREADS - 1) height = tmx > tmy ? rx[my] : ry[mx];
             ArgMinT rbest = {__builtin_inf(), 0x7fffffff, 0};   // minimum of the new row: the merged cluster's own cache entry
-            // dirty partners first (their loads overlap the streaming pass); results are stored after
-            // the streaming pass has rewritten row y
-            double dv = 0.0; int dd = -1;
+            double dxi = 0.0, dyi = 0.0, nvd = 0.0; int dd = -1;
             if (tid < D) {
                 const int d = dslot[tid];
                 if (d >= 0 && d != my && ((alive[d >> 5] >> (d & 31)) & 1u)) {
-                    const double dxi = dtime[tid] > tmx ? W[(int64_t)d * ld + mx] : rx[d];
-                    const double dyi = dtime[tid] > tmy ? W[(int64_t)d * ld + my] : ry[d];
-                    const double nvd = nnval_ld[d];
-                    dv = div_by_small_int(fx * dxi + fy * dyi, fs, rcp);
+                    dxi = dtime[tid] > tmx ? W[(int64_t)d * ld + mx] : rx[d];
+                    dyi = dtime[tid] > tmy ? W[(int64_t)d * ld + my] : ry[d];
+                    nvd = nnval_ld[d];
                     dd = d;
-                    const uint32_t id = nnidx[d];
-                    if (id == (uint32_t)mx || id == (uint32_t)my) nnidx[d] = (uint16_t)NN_NOIDX;
-                    else if (id != NN_NOIDX && dv <= nvd) {
-                        if (dv < nvd) nnidx[d] = (uint16_t)NN_NOIDX;
-                        else { if ((uint32_t)my < id) nnidx[d] = (uint16_t)my; atomicOr(&tieb[d >> 5], 1u << (d & 31)); }
-                    }
                 }
             }
 #pragma unroll 4
@@ -729,14 +723,25 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_nc(double* __restrict__
                 }
                 *reinterpret_cast<double2*>(ry + j) = b;
             }
-            if (dd >= 0) rbest = argmint_join(rbest, dv, dd, 0);
-            rbest = argmint_wave(rbest);
+            double dv = 0.0;
+            if (dd >= 0) {                                     // the dirty partner: its new distance, its cache entry
+                dv = div_by_small_int(fx * dxi + fy * dyi, fs, rcp);
+                const uint32_t id = nnidx[dd];
+                if (id == (uint32_t)mx || id == (uint32_t)my) nnidx[dd] = (uint16_t)NN_NOIDX;
+                else if (id != NN_NOIDX && dv <= nvd) {
+                    if (dv < nvd) nnidx[dd] = (uint16_t)NN_NOIDX;
+                    else { if ((uint32_t)my < id) nnidx[dd] = (uint16_t)my; atomicOr(&tieb[dd >> 5], 1u << (dd & 31)); }
+                }
+                rbest = argmint_join(rbest, dv, dd, 0);
+            }
+            if (tid == NN_THREADS - 1) zraw[4 * (int64_t)step + 2] = height;
+            rbest = argmint_wave_fast(rbest);
             if (lane == 0) { s_v[wave] = rbest.v; s_i[wave] = rbest.i; s_t[wave] = rbest.t; }
             __syncthreads();
             if (dd >= 0) ry[dd] = dv;
             if (wave == 0) {
                 ArgMinT m = {lane < 16 ? s_v[lane] : __builtin_inf(), lane < 16 ? s_i[lane] : 0x7fffffff, lane < 16 ? s_t[lane] : 0};
-                m = argmint_row16(m);
+                m = argmint_row16_fast(m);
                 if (lane == 0) {                             // cluster y is dirty from now on; its neighbour is known
                     if (s_ey >= 0) dslot[s_ey] = -1;         // its older entry is superseded
                     dslot[D] = my; dtime[D] = step;

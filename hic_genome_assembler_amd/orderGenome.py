@@ -660,7 +660,7 @@ def chromosomesOfRank(chromList, rank, world):
 
 
 def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds=6, scanScaffolds=5, plotChrom=True,
-                showPlot=True, savePlotDir=False, plotTitleSuffix=False, shard=None):
+                showPlot=True, savePlotDir=False, plotTitleSuffix=False, shard=None, on_native_phase=None):
     """OG:591-628.  Chromosomes are independent (OG:608-612), so they are ordered concurrently:
     one host thread + one libhicmi context (own HIP stream, own scratch) per chromosome in flight,
     all reading the same device-resident contact matrix.  Results are collected in file order.
@@ -713,6 +713,8 @@ def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds
                 if job is not None:
                     jobs.append((lanes[i].ctx,) + job)
                     job_of.append(i)
+            if on_native_phase is not None:
+                on_native_phase()                     # a long native call follows: background Python work may take the GIL
             for i, (ids, rev, best) in zip(job_of, matrix.ctx.p2_insert_all_multi(jobs)):
                 st = states[i]
                 inserted[i] = (_insertion_result(ids, rev, st["ordered"], st["rest"], lanes[i]), best)
@@ -846,7 +848,7 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, chromosomeGroup
 
 def runResident(adjMat: GenomeMatrix, binList, chromosomeGroupFile, chromosomeOrderFile, plotOrderFile,
                 nScaffolds, scanScaffolds, resolution, savePlotDir=False, plotTitleSuffix=False, shard=None,
-                chromosomeList=None):
+                chromosomeList=None, on_native_phase=None):
     """OG:691-709 on contacts that are already resident in HBM (what bench.py times).  ``binList``
     gives the bin of every row of the device matrix; bins that Part 1 did not assign to a group are
     simply never selected, which is what the reference's re-load restricted to grouped bins
@@ -861,7 +863,8 @@ def runResident(adjMat: GenomeMatrix, binList, chromosomeGroupFile, chromosomeOr
             print("Nodes found " + str(sum(len(c) for c in chromosomeList)))
         orderedChromosomes = orderGenome(adjMat, chromosomeList, binList, resolution, nScaffolds=nScaffolds,
                                          scanScaffolds=scanScaffolds, plotChrom=True, showPlot=False,
-                                         savePlotDir=savePlotDir, plotTitleSuffix=plotTitleSuffix, shard=shard)
+                                         savePlotDir=savePlotDir, plotTitleSuffix=plotTitleSuffix, shard=shard,
+                                         on_native_phase=on_native_phase)
         if shard is None or shard[0] == 0:
             writeScaffoldOrderingsToFile(orderedChromosomes, chromosomeOrderFile)
             writeBinIDsOrderingToFile([s for group in orderedChromosomes for s in group], plotOrderFile)

@@ -485,21 +485,35 @@ def runPipeline(hicProBedFile, hicProBiasFile, hicProMatrixFile, hicProScaffSize
 
 
 class _FileWriter:
-    """Part 1's text files written on one background thread while the device (and then Part 2) keeps working: the
-    strings are built and written in submission order; ``finish()`` returns when every file is on disk and re-raises
-    what a writer raised."""
+    """Part 1's text files written on one background thread while the device keeps working: the strings are built and
+    written in submission order; ``finish()`` returns when every file is on disk and re-raises what a writer raised.
+    Jobs submitted with ``deferred=True`` wait for ``release()``: formatting 16,000 lines holds the interpreter lock, so
+    the caller releases them when it enters a long native call (Part 2's lock-step insertion), not while its own
+    Python threads are busy."""
 
     def __init__(self, enabled):
+        import threading
         from concurrent.futures import ThreadPoolExecutor
         self.pool = ThreadPoolExecutor(max_workers=1) if enabled else None
+        self.gate = threading.Event()
         self.jobs = []
 
-    def submit(self, fn, *args):
+    def submit(self, fn, *args, deferred=False):
         if self.pool is None:
             return fn(*args)
-        self.jobs.append(self.pool.submit(fn, *args))
+        if deferred:
+            def held(*a):
+                self.gate.wait()
+                return fn(*a)
+            self.jobs.append(self.pool.submit(held, *args))
+        else:
+            self.jobs.append(self.pool.submit(fn, *args))
+
+    def release(self):
+        self.gate.set()
 
     def finish(self):
+        self.gate.set()
         for j in self.jobs:
             j.result()
         self.jobs = []
@@ -518,9 +532,11 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
     ``overlap_files=True``: the four files are written by a background thread (the dendrogram order while the rows
     are sorted and scanned, the three group files while the caller goes on); the caller hands
     ``adjMat.chromosome_groups`` - what Part 2 would read back from chromosomeGroupFile - to
-    ``orderGenome.runResident(..., chromosomeList=)`` and calls ``adjMat.finish_files()`` before it uses the files."""
+    ``orderGenome.runResident(..., chromosomeList=, on_native_phase=adjMat.release_files)`` and calls
+    ``adjMat.finish_files()`` before it uses the files."""
     writer = _FileWriter(overlap_files)
     adjMat.finish_files = writer.finish
+    adjMat.release_files = writer.release
     with paused_gc():
         t0 = time.time()
         if shard is not None:
@@ -553,15 +569,16 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
                 new_order, cutIndices = louvain.modularity_remaining_data(louvain.log_transform(sim_tail), binList,
                                                                           cutIndices, n_rounds=louvainRounds)
                 adjMat, binList = reorderMatrix(adjMat, binList, new_order)
-        writer.submit(writeBinGroupingsToFile, list(cutIndices), list(binList), binGroupFile)
+        writer.submit(writeBinGroupingsToFile, list(cutIndices), list(binList), binGroupFile, deferred=True)
         binGroups = _bin_group_pairs(cutIndices, binList)
         print("Total run-time to identify chromosome boundaries = " + str(time.time() - t0))
         t0 = time.time()
         fastaSizeDict = readSizeFileToDict(hicProScaffSizeFile)
         print(str(len(binGroups)) + " chromosomes read in from file")      # == readBinGroupingsFromFile(binGroupFile)
-        chrGroups = assessChromosomeClustering(binGroups, assessmentFile, write=writer.submit)
+        chrGroups = assessChromosomeClustering(binGroups, assessmentFile,
+                                               write=lambda fn, *a: writer.submit(fn, *a, deferred=True))
         adjMat.chromosome_groups = rankChromosomeGroups(chrGroups, fastaSizeDict)
-        writer.submit(writeChromosomeGroupingsToFile, chrGroups, fastaSizeDict, chromosomeGroupFile)
+        writer.submit(writeChromosomeGroupingsToFile, chrGroups, fastaSizeDict, chromosomeGroupFile, deferred=True)
         print("Total run-time to assign scaffolds to chromosomes = " + str(time.time() - t0))
     if not overlap_files:
         writer.finish()

@@ -30,7 +30,16 @@ def summarize(directory):
 
 if __name__ == "__main__":
     res = {}
-    for directory in sys.argv[1:]:
-        counter = "FETCH_SIZE" if "FETCH" in os.path.basename(directory.rstrip("/")) else "WRITE_SIZE"
-        res[counter] = summarize(directory)
+    args = sys.argv[1:]
+    if args and args[0] == "--any":            # any counters: the directory name ends in _<COUNTER>; values summed per kernel
+        for directory in args[1:]:
+            if not os.path.isdir(directory):
+                continue
+            base = os.path.basename(directory.rstrip("/"))
+            counter = base.split("_pmc_mfma_")[-1] if "_pmc_mfma_" in base else base
+            res[counter] = {k: {"dispatches": v["dispatches"], "sum": v["sum_KB"]} for k, v in summarize(directory).items()}
+    else:
+        for directory in args:
+            counter = "FETCH_SIZE" if "FETCH" in os.path.basename(directory.rstrip("/")) else "WRITE_SIZE"
+            res[counter] = summarize(directory)
     json.dump(res, sys.stdout, indent=1)

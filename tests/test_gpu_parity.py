@@ -607,6 +607,34 @@ def test_pipeline_fused_decision_steps_identical_to_reference(hic, name, tmp_pat
             assert fh.read() == gc.golden_text(name, fn), fn
 
 
+@pytest.mark.parametrize("name", ["n600", "n300_edges"])
+def test_resident_path_with_background_file_writer(hic, name, tmp_path):
+    """What bench.py times: runResident with the four Part 1 files written by a background thread, Part 2 started from
+    the in-memory groups (DeviceMatrix.chromosome_groups) instead of reading chromosomeGroups.txt back, finish_files()
+    at the end - the six files must be the reference's."""
+    from hic_genome_assembler_amd import orderGenome as p2, scaffoldToChromosomes as p1
+    from hic_genome_assembler_amd.hostio import initiateLoci
+    spec, meta, gold, lay, c = gc.load_case(name)
+    paths = gc.write_case_files(name, str(tmp_path))
+    f = lambda k: os.path.join(str(tmp_path), k)  # noqa: E731
+    bins = initiateLoci(paths["hicProBedFile"], paths["hicProBiasFile"])
+    dm = p1.buildAdjacencyMatrix(paths["hicProMatrixFile"], bins)
+    try:
+        p1.runResident(dm, bins, paths["hicProScaffSizeFile"], f("dendrogramOrder.txt"), f("binGroups.txt"),
+                       f("assessment.txt"), f("chromosomeGroups.txt"), spec["min_size"], 0.0, spec["psig"], overlap_files=True)
+        assert dm.chromosome_groups is not None
+        p2.runResident(p2.GenomeMatrix(dm.ctx), dm.kept_bins, f("chromosomeGroups.txt"), f("chromosomeOrders.txt"),
+                       f("plotOrder.txt"), spec["n_scaffolds"], spec["scan_scaffolds"], 100000,
+                       chromosomeList=dm.chromosome_groups, on_native_phase=dm.release_files)
+        dm.finish_files()
+    finally:
+        dm.ctx.close()
+    assert dm.chromosome_groups == p2.readChromsFromFile(f("chromosomeGroups.txt"))
+    for fn in gc.OUTPUT_FILES:
+        with open(f(fn)) as fh:
+            assert fh.read() == gc.golden_text(name, fn), fn
+
+
 def test_cli_drop_in(hic, tmp_path):
     from hic_genome_assembler_amd import run_hicAssembler, synth
     name = "n160"
@@ -887,15 +915,15 @@ def test_fp32_contacts_are_widened_exactly(hic):
                 assert np.array_equal(z32, z64) and np.array_equal(l32, l64)
 
 
-@pytest.mark.parametrize("n,sorter", [(16500, "radix"), (16500, "bitonic"), (8193, "radix"), (64000, "radix")])
+@pytest.mark.parametrize("n,sorter", [(16500, "bitonic"), (16500, "radix"), (8193, "radix"), (64000, "bitonic"), (64000, "radix")])
 def test_row_sort_across_tiles_with_ties(hic, monkeypatch, n, sorter):
     """Rows longer than one tile (8192 elements for the LSD radix kernel, 16384 for the bitonic networks) are sorted
     tile by tile and combined - by lower bounds in the other tiles / by merge levels through the scratch buffer; with
     quantised contacts (heavy ties) the order must still be "stable ascending, reversed" of the similarity row.
     64,000 columns: the row length of BASELINE configs[4]."""
     import torch
-    if sorter == "bitonic":
-        monkeypatch.setenv("HICMI_SORT_BITONIC", "1")
+    if sorter == "radix":                                      # the default is the bitonic network (faster on MI355X)
+        monkeypatch.setenv("HICMI_SORT_RADIX", "1")
     g = torch.Generator(device="cuda:0")
     g.manual_seed(5)
     c = torch.randint(0, 40, (n, n), generator=g, device="cuda:0").to(torch.float64)

@@ -176,7 +176,7 @@ def _check_stages_and_run(hic, lay, contacts, out_dir):
 
 
 _EARLIER = {"HICMI_P2_HOST_INSERT": "1", "HICMI_P2_WINDOW_DIRECT": "1", "HICMI_PART2_LOCKSTEP": "0", "HICMI_NNCHAIN_WGS": "1",
-            "HICMI_NNCHAIN_PLAIN": "1", "HICMI_SORT_BITONIC": "1"}
+            "HICMI_NNCHAIN_PLAIN": "1", "HICMI_SORT_RADIX": "1"}
 
 _VARIANT_RUN = r"""
 import contextlib, io, os, sys
@@ -206,7 +206,7 @@ ctx.close()
 def test_full_pipeline_at_baseline_size(n, f32, tmp_path):
     """configs[3] (32,000 bins) and configs[4] (64,000 bins, fp32 contacts) on one GPU: the full resident -part1 -part2
     with the property checks of _check_stages_and_run, then the same map through the earlier implementations
-    (single-workgroup nn-chain without the neighbour cache, bitonic row sort, host-decided insertion, per-candidate window
+    (single-workgroup nn-chain without the neighbour cache, LSD radix row sort, host-decided insertion, per-candidate window
     kernels, one queue per chromosome) in a second process: the six files must be identical."""
     from hic_genome_assembler_amd import _lib as hic
     seed = 3 if n == 32000 else 5
