@@ -124,6 +124,29 @@ def cpu_baseline(sample_bins, n_scaffolds, scan_scaffolds, work):
                           calls["n"]))
 
 
+def e2e_cli(n_bins, work):
+    """Text in, six files out through the drop-in CLI (`run_hicAssembler.py -part1 -part2`, plots off) on a small map:
+    what a user of the reference's command line pays besides the resident hot path - HiC-Pro text parsing (once: the matrix
+    stays in HBM for Part 2), upload, both parts, files.  16,000 bins are not run here: writing that .matrix file (128 M
+    triplets) takes minutes; its parse alone is 3.4 s."""
+    from hic_genome_assembler_amd import run_hicAssembler, synth
+    lay = synth.make_layout(n_bins, seed=1)
+    c = synth.dense_contacts(lay, seed=1, sinkhorn_iters=12)
+    paths = synth.write_hicpro(os.path.join(work, "in"), lay, c, "e2e")
+    cfg = synth.write_config(os.path.join(work, "config.txt"), paths, os.path.join(work, "out"), os.path.join(work, "plots"),
+                             lay.resolution, min_size=5, modularity=0.0, psig=0.05, n_scaffolds=6, scan_scaffolds=5)
+    os.environ["HICMI_NO_PLOTS"] = "1"
+    times = []
+    for _ in range(2):                                     # second run: page cache warm, HIP modules loaded
+        t0 = time.time()
+        run_hicAssembler.main(["-part1", "-part2", "-c", cfg])
+        times.append(time.time() - t0)
+    size = os.path.getsize(paths["hicProMatrixFile"])
+    return {"bins": n_bins, "seconds_first_run": round(times[0], 3), "seconds_second_run": round(times[1], 3),
+            "matrix_text_MB": round(size / 1e6, 1),
+            "what": "run_hicAssembler.py -part1 -part2 -config: HiC-Pro text -> six files, plots off, matrix parsed once"}
+
+
 def pmc_traffic(n, fam):
     """HBM bytes per launch of a kernel family from the latest committed rocprofv3 --pmc collection for this map size
     (profiles/r*_pmc_part1_<n/1000>k.json; 2 x FETCH_SIZE + WRITE_SIZE: MI355X_MICROARCH.md, FETCH_SIZE counts half
@@ -275,6 +298,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-32k", action="store_true", help="skip the north_star_32k object")
     ap.add_argument("--no-table", action="store_true", help="skip the extra untimed step behind roofline_all")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the text-to-files run of the CLI at 2,000 bins")
     ap.add_argument("--weak", action="store_true",
                     help="N > 1: one independent map per rank (weak scaling) instead of ONE map over all ranks")
     ap.add_argument("--one-map", action="store_true", help="(default for N > 1; kept for earlier command lines)")
@@ -370,6 +394,14 @@ def main():
             shutil.rmtree(work, ignore_errors=True)
         else:
             out["cpu_baseline"] = None
+        if not args.no_e2e and not args.no_cpu_baseline and world == 1:
+            work = tempfile.mkdtemp(prefix="hicbench_e2e_")
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    out["e2e"] = e2e_cli(2000, work)
+            except SystemExit:
+                out["e2e"] = None
+            shutil.rmtree(work, ignore_errors=True)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -188,6 +188,9 @@ __device__ __forceinline__ void rb_shuffle_stage(uint64_t (&K)[RB_E], uint32_t (
         const uint32_t oi = __shfl_xor(I[q], m, 64);
         const bool other_lt = RB_LT(ok, oi, K[q], I[q]);
         if (other_lt == keep_min) { K[q] = ok; I[q] = oi; }
+        // four exchanges in flight at a time: with all sixteen hoisted the kernel needed 204 bytes of scratch per lane - spills
+        // inside the stages, 1.7 GB of write traffic for a 0.5 GB result in the round-1 counters
+        if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -253,14 +256,18 @@ __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
     uint16_t* xi = reinterpret_cast<uint16_t*>(smem + (size_t)(RB_E / 2) * RB_T * sizeof(uint64_t));
     const int tile = P < RB_TILE ? P : RB_TILE;            // P >= RB_E (launcher)
     const int ntiles = P / tile;
-    const int tid = threadIdx.x;
-    const bool live = RB_E * tid < tile;                    // short rows use the first tile / RB_E lanes
+    const int tid0 = threadIdx.x;
+    const bool live = RB_E * tid0 < tile;                   // short rows use the first tile / RB_E lanes
     uint64_t* gk = skeys + (size_t)blockIdx.x * (size_t)P;
     uint16_t* gi = sidx + (size_t)blockIdx.x * (size_t)P;
     uint64_t K[RB_E];
     uint32_t I[RB_E];
 
     for (int row = row_first + blockIdx.x * row_stride; row < n; row += gridDim.x * row_stride) {   // this shard's rows
+        // the lane index is re-read through an opaque statement per row: otherwise lane-dependent addresses are hoisted out
+        // of the row loop, spilled, and re-loaded / re-stored in every row (1.2 GB of scratch writes per 16k map)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
         const int pa = order[row];
         const double sig = np_sum[pa], rs = seq_sum[pa];
         const double* __restrict__ crow = C + (int64_t)pa * ldc;
@@ -289,7 +296,9 @@ __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
             rb_inreg_tail(K, I, ((base + RB_E * tid) & RB_E) == 0, RB_E / 2);                   // level RB_E: per lane
             for (int k = 2 * RB_E; k <= tile; k <<= 1) rb_tile_stages(K, I, tid, base, k, k >> 1, xk, xi);
             if (ntiles == 1) {
-                if (live) rb_store_reversed(out, n, RB_E * tid, I);
+                int tid2 = tid;                             // (output addresses formed here, not before the sort and spilled)
+                asm volatile("" : "+v"(tid2));
+                if (live) rb_store_reversed(out, n, RB_E * tid2, I);
             } else {
 #pragma unroll
                 for (int q = 0; q < RB_E; q++) { gk[base + RB_E * tid + q] = K[q]; gi[base + RB_E * tid + q] = (uint16_t)I[q]; }
@@ -310,8 +319,11 @@ __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
 #pragma unroll
                 for (int q = 0; q < RB_E; q++) { K[q] = gk[base + RB_E * tid + q]; I[q] = gi[base + RB_E * tid + q]; }
                 rb_tile_stages(K, I, tid, base, k, tile >> 1, xk, xi);
-                if (k == P) rb_store_reversed(out, n, base + RB_E * tid, I);
-                else {
+                if (k == P) {
+                    int tid2 = tid;
+                    asm volatile("" : "+v"(tid2));
+                    rb_store_reversed(out, n, base + RB_E * tid2, I);
+                } else {
 #pragma unroll
                     for (int q = 0; q < RB_E; q++) { gk[base + RB_E * tid + q] = K[q]; gi[base + RB_E * tid + q] = (uint16_t)I[q]; }
                 }
