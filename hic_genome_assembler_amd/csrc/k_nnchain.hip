@@ -1281,7 +1281,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
                     while (first_ptr < n && !((alive[first_ptr >> 5] >> (first_ptr & 31)) & 1u)) first_ptr++;
                     chain[0] = first_ptr; ring[0] = first_ptr; ring_lo = 0; top = first_ptr; second = -1; len = 1; lowmark = 0;
                 }
-                int act = 0;                                 // 1: scan row `top`, 2: merge (top, second), 3: stop
+                int act = stop_code ? 3 : 0;                 // 1: scan row `top`, 2: merge (top, second), 3: stop
                 while (act == 0) {
                     const int x = top, prev = (len > 1) ? second : -1;
                     const uint32_t idx = nnidx[x];
@@ -1434,6 +1434,34 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
         }
         __syncthreads();
         const int mx = s_mx, my = s_my, a = s_a, aprev = s_prev;
+        // lane 0, once the exchange has delivered the merged row's minimum and row a's: cluster y is dirty from now on and its
+        // neighbour is known; the fused scan of row a is decided exactly like a scan on its own
+        auto after_exchange = [&]() {
+            if (s_ey >= 0) dslot[s_ey] = -1;
+            dslot[D] = my; dtime[D] = step;
+            atomicAnd(&smask[my >> 5], ~(1u << (my & 31)));
+            if (s_my_i >= 0 && s_my_i < n) {
+                nnidx[my] = (uint16_t)s_my_i;
+                if (s_my_t) atomicOr(&tieb[my >> 5], 1u << (my & 31)); else atomicAnd(&tieb[my >> 5], ~(1u << (my & 31)));
+                if (my >= c0 && my < c1) w.nnval[my] = s_my_v;
+            } else nnidx[my] = (uint16_t)NN_NOIDX;
+            if (a >= 0) {
+                if (s_a_i < 0 || s_a_i >= n) stop_code = NN_STOP_GUARD;
+                else {
+                    nnidx[a] = (uint16_t)s_a_i;
+                    if (s_a_t) atomicOr(&tieb[a >> 5], 1u << (a & 31)); else atomicAnd(&tieb[a >> 5], ~(1u << (a & 31)));
+                    if (a >= c0 && a < c1) w.nnval[a] = s_a_v;
+                    int y = s_a_i;
+                    if (aprev >= 0 && !(s_a_v < s_dprev)) y = aprev;
+                    if (y != aprev) {
+                        if (++guard > 4 * n + 8) stop_code = NN_STOP_GUARD;
+                        chain[len] = y; ring[len & 255] = y;
+                        if (len - 255 > ring_lo) ring_lo = len - 255;
+                        second = top; top = y; len++;
+                    } else nnidx[a] = (uint16_t)aprev;
+                }
+            }
+        };
         if (tid < D) {
             if (dslot[tid] == mx) s_tx = dtime[tid];
             if (dslot[tid] == my) { s_ty = dtime[tid]; s_ey = tid; }
@@ -1632,50 +1660,26 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
                     s_my_v = m.v; s_my_i = m.i; s_my_t = m.t;
                     s_a_v = av; s_a_i = ai; s_a_t = at;
                     s_ev = 0;
+                    // the common case - nobody is late, no slice lost its cache - is finished right here by the lane that holds the
+                    // results: no barrier between the exchange and the bookkeeping, none between the bookkeeping and the next walk
+                    if (!late && (evm & 0xffffull) == 0ull) after_exchange();
                 }
             }
             __syncthreads();
             if (s_stop) { stopped = true; break; }
-            const int evmask = s_evmask;
-            if (evmask) {                                          // rare: whole slices lose their cache entries
+            if (s_evmask) {                                        // rare: whole slices lose their cache entries first
+                const int evmask = s_evmask;
                 for (int g = 0; g < NWG; g++) {
                     if (!((evmask >> g) & 1)) continue;
                     const int g0 = g * slice < n ? g * slice : n, g1 = g0 + slice < n ? g0 + slice : n;
                     for (int i = g0 + tid; i < g1; i += NN_THREADS) nnidx[i] = (uint16_t)NN_NOIDX;
                 }
                 __syncthreads();
-            }
-            if (tid == 0) {
-                // cluster y is dirty from now on; its neighbour is known
-                if (s_ey >= 0) dslot[s_ey] = -1;
-                dslot[D] = my; dtime[D] = step;
-                atomicAnd(&smask[my >> 5], ~(1u << (my & 31)));
-                if (s_my_i >= 0 && s_my_i < n) {
-                    nnidx[my] = (uint16_t)s_my_i;
-                    if (s_my_t) atomicOr(&tieb[my >> 5], 1u << (my & 31)); else atomicAnd(&tieb[my >> 5], ~(1u << (my & 31)));
-                    if (my >= c0 && my < c1) w.nnval[my] = s_my_v;
-                } else nnidx[my] = (uint16_t)NN_NOIDX;
-                if (a >= 0) {                                      // the fused scan of row a: same decision as a scan on its own
-                    if (s_a_i < 0 || s_a_i >= n) { s_stop = NN_STOP_GUARD; stop_code = NN_STOP_GUARD; }
-                    else {
-                        nnidx[a] = (uint16_t)s_a_i;
-                        if (s_a_t) atomicOr(&tieb[a >> 5], 1u << (a & 31)); else atomicAnd(&tieb[a >> 5], ~(1u << (a & 31)));
-                        if (a >= c0 && a < c1) w.nnval[a] = s_a_v;
-                        int y = s_a_i;
-                        if (aprev >= 0 && !(s_a_v < s_dprev)) y = aprev;
-                        if (y != aprev) {
-                            if (++guard > 4 * n + 8) { s_stop = NN_STOP_GUARD; stop_code = NN_STOP_GUARD; }
-                            chain[len] = y; ring[len & 255] = y;
-                            if (len - 255 > ring_lo) ring_lo = len - 255;
-                            second = top; top = y; len++;
-                        } else nnidx[a] = (uint16_t)aprev;
-                    }
-                }
+                if (tid == 0) after_exchange();
             }
             D++;
         }
-        __syncthreads();
-        if (s_stop) break;
+        // no barrier here: lane 0 goes straight into the next walk, everybody else to the barrier behind it
         if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[2] += t1 - t0; }
     }
     __syncthreads();

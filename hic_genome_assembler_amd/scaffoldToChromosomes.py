@@ -116,11 +116,35 @@ def convertMatrix(adjacencyMatrix: DeviceMatrix, binList, distance=True, similar
     return adjacencyMatrix
 
 
-def averageClusterNodes(adjacencyMatrix: DeviceMatrix, nodeLabels, noPlot=True):
+def averageClusterNodes(adjacencyMatrix: DeviceMatrix, nodeLabels, noPlot=True, meanwhile=None):
     """S2C:187-208: UPGMA + count-sorted leaf order.  Returns a dict with the two keys of SciPy's
-    dendrogram object the reference uses ('ivl', 'leaves') plus the linkage matrix 'Z'."""
+    dendrogram object the reference uses ('ivl', 'leaves') plus the linkage matrix 'Z'.
+    ``meanwhile``: host work that does not need the tree; it runs on this thread while the chain - one native call of
+    ~100 ms that releases the interpreter lock - runs on another (``nodeLabels`` may then be a callable returning the
+    labels: it is called after ``meanwhile``)."""
     t0 = time.time()
-    leaves, z = adjacencyMatrix.ctx.upgma(want_linkage=True)
+    if meanwhile is None:
+        leaves, z = adjacencyMatrix.ctx.upgma(want_linkage=True)
+    else:
+        import threading
+        box = {}
+
+        def chain():
+            try:
+                box["out"] = adjacencyMatrix.ctx.upgma(want_linkage=True)
+            except BaseException as exc:          # re-raised on the calling thread
+                box["err"] = exc
+        th = threading.Thread(target=chain)
+        th.start()
+        try:
+            meanwhile()
+        finally:
+            th.join()
+        if "err" in box:
+            raise box["err"]
+        leaves, z = box["out"]
+    if callable(nodeLabels):
+        nodeLabels = nodeLabels()
     print("Time to cluster " + str(time.time() - t0))
     leaves = np.asarray(leaves).tolist()
     return {"ivl": [nodeLabels[i] for i in leaves], "leaves": leaves, "Z": z}
@@ -393,16 +417,21 @@ def _write_text(path, text):
         fh.write(text)
 
 
-def assessChromosomeClustering(chromList, statsFile, percentToAssign=51., write=None):
-    """S2C:1038-1077.  ``chromList``: groups of bin-grouping lines (``ID<TAB>scaffold<TAB>...``).  ``write``: called as
-    ``write(fn, *args)`` to put the report on disk (default: at once)."""
-    groups = [_pairs_of_lines(grp) for grp in chromList]
+def _scaffold_bins(pairs):
+    """{scaffold: [[bin, scaffold], ...] with the bins ascending} over (bin, scaffold) pairs (S2C:1043-1053)."""
     scaffolds = {}
-    for grp in groups:
-        for bin_id, scaff in grp:
-            scaffolds.setdefault(scaff, []).append(int(bin_id))
-    # every entry is [bin, scaffold], a scaffold's bins in ascending order
-    scaffolds = {s: [[b, s] for b in sorted(ids)] for s, ids in scaffolds.items()}
+    for bin_id, scaff in pairs:
+        scaffolds.setdefault(scaff, []).append(int(bin_id))
+    return {s: [[b, s] for b in sorted(ids)] for s, ids in scaffolds.items()}
+
+
+def assessChromosomeClustering(chromList, statsFile, percentToAssign=51., write=None, scaffolds=None):
+    """S2C:1038-1077.  ``chromList``: groups of bin-grouping lines (``ID<TAB>scaffold<TAB>...``).  ``write``: called as
+    ``write(fn, *args)`` to put the report on disk (default: at once).  ``scaffolds``: the scaffold -> bins table when
+    the caller has built it already (it does not depend on the grouping: every bin is in exactly one group)."""
+    groups = [_pairs_of_lines(grp) for grp in chromList]
+    if scaffolds is None:
+        scaffolds = _scaffold_bins(p for grp in groups for p in grp)
     final, false_pos, assigned, out = [], 0, 0, []
     for k, grp in enumerate(groups):
         out.append("### Chromosome" + str(k + 1) + " ###\n")
@@ -547,8 +576,15 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
         adjMat, binList = removeRows(adjMat, binList, zeroRows=True, biasVals=False)
         adjMat.kept_bins = list(binList)                  # rows of the device matrix, in .bed order
         adjMat = convertMatrix(adjMat, binList, distance=True, similarity=False)
-        dendroLabels = [b.chrom + '_' + str(b.ID) for b in binList]
-        dendrogram = averageClusterNodes(adjMat, dendroLabels, noPlot=True)
+        # host work that does not depend on the tree runs while the chain does (a single ~100 ms native call): the labels,
+        # the size table and the scaffold -> bins table of the assessment
+        prep = {}
+
+        def meanwhile(bl=binList):
+            prep["labels"] = [b.chrom + '_' + str(b.ID) for b in bl]
+            prep["sizes"] = readSizeFileToDict(hicProScaffSizeFile)
+            prep["scaffolds"] = _scaffold_bins((b.ID, b.chrom) for b in bl)
+        dendrogram = averageClusterNodes(adjMat, lambda: prep["labels"], noPlot=True, meanwhile=meanwhile)
         writer.submit(dendrogramLeafOrder_toFile, dendrogram, dendrogramOrderFile)
         # the reference parses the file back (readDengrogramLeavesFromFile); the leaves are the same integers
         adjMat, binList = reorderMatrix(adjMat, binList, dendrogram['leaves'])
@@ -573,10 +609,11 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
         binGroups = _bin_group_pairs(cutIndices, binList)
         print("Total run-time to identify chromosome boundaries = " + str(time.time() - t0))
         t0 = time.time()
-        fastaSizeDict = readSizeFileToDict(hicProScaffSizeFile)
+        fastaSizeDict = prep["sizes"]
         print(str(len(binGroups)) + " chromosomes read in from file")      # == readBinGroupingsFromFile(binGroupFile)
         chrGroups = assessChromosomeClustering(binGroups, assessmentFile,
-                                               write=lambda fn, *a: writer.submit(fn, *a, deferred=True))
+                                               write=lambda fn, *a: writer.submit(fn, *a, deferred=True),
+                                               scaffolds=None if (modularity is not False and modularity > 0.0) else prep["scaffolds"])
         adjMat.chromosome_groups = rankChromosomeGroups(chrGroups, fastaSizeDict)
         writer.submit(writeChromosomeGroupingsToFile, chrGroups, fastaSizeDict, chromosomeGroupFile, deferred=True)
         print("Total run-time to assign scaffolds to chromosomes = " + str(time.time() - t0))
