@@ -204,6 +204,7 @@ class Job:
         self.ctx = _lib.Context(local)
         self.bins = make_bins(self.lay, Bin)               # the .bed metadata, parsed once like the matrix
         self.last = {}
+        self.parts = [0.0, 0.0, 0]                         # host seconds in Part 1 / Part 2 and steps, since the timed region began
 
     def f(self, k):
         return os.path.join(self.work, k)
@@ -230,6 +231,7 @@ class Job:
             dm.finish_files()
         self.last["part2_s"] = time.perf_counter() - ta - self.last["part1_s"]
         self.last["cuts"] = cuts
+        self.parts[0] += self.last["part1_s"]; self.parts[1] += self.last["part2_s"]; self.parts[2] += 1
 
     def close(self):
         self.ctx.close()
@@ -243,6 +245,7 @@ def timed_run(job, steps, warmup, timing_mode, barrier, reduce_dev):
         job.step()
     job.ctx.timing_enable(timing_mode)
     job.ctx.timing_reset()
+    job.parts = [0.0, 0.0, 0]
     barrier()
     torch.cuda.synchronize()
     job.ctx.synchronize()
@@ -353,8 +356,8 @@ def main():
                        "scaffolds": len(lay.scaffold_names), "cuts_found": len(last.get("cuts", [])),
                        "minSize": 5, "modularity": 0, "psig": 0.05, "nScaffolds": args.n_scaffolds,
                        "scanScaffolds": args.scan_scaffolds, "wall_clock_s": ms_per_step / 1e3,
-                       "last_step_part1_s": round(last.get("part1_s", 0.0), 4),
-                       "last_step_part2_s": round(last.get("part2_s", 0.0), 4),
+                       "part1_s_per_step": round(job.parts[0] / max(job.parts[2], 1), 4),
+                       "part2_s_per_step": round(job.parts[1] / max(job.parts[2], 1), 4),
                        "part2_workers": p2.WORKERS, "ranks": world,
                        "parallelism": ("ONE map over %d ranks: Part 1's row-independent stages (row sums, row sort / rank "
                                        "matrix, cut and filter counts) row-blocked with an all-gather of the per-row counts, "
@@ -379,8 +382,8 @@ def main():
         ms32 = e32 / k32 * 1e3
         out["north_star_32k"] = {"workload": workload_label(32000, False), "value": 32000 / (ms32 / 1e3), "unit": "bins/s",
                                  "ms_per_step": ms32, "steps": k32, "warmup": 1, "cuts_found": len(job32.last.get("cuts", [])),
-                                 "last_step_part1_s": round(job32.last.get("part1_s", 0.0), 4),
-                                 "last_step_part2_s": round(job32.last.get("part2_s", 0.0), 4),
+                                 "part1_s_per_step": round(job32.parts[0] / max(job32.parts[2], 1), 4),
+                                 "part2_s_per_step": round(job32.parts[1] / max(job32.parts[2], 1), 4),
                                  "roofline": roofline_of(t32, s32, k32, 32000, max(1, min(p2.WORKERS, 8))),
                                  "kernels_ms_per_step": {k: round(v["ms"] / k32, 3) for k, v in t32.items() if v["ms"] > 0}}
         job32.close()

@@ -39,6 +39,7 @@ SIGNATURES = {
     "hicmi_compact": (ctypes.c_int, [_vp, _vp, c_i64]),
     "hicmi_upgma": (ctypes.c_int, [_vp, _vp, _vp]),
     "hicmi_rank_matrix": (ctypes.c_int, [_vp, _vp]),
+    "hicmi_presort_state": (ctypes.c_int, [_vp, _vp, _vp]),
     "hicmi_get_rank_rows": (ctypes.c_int, [_vp, c_i64, c_i64, ctypes.c_int, _vp]),
     "hicmi_get_similarity_row": (ctypes.c_int, [_vp, c_i64, _vp]),
     "hicmi_cut_scan": (ctypes.c_int, [_vp, c_i64, c_i64, c_dbl, _vp, _vp]),
@@ -278,6 +279,15 @@ class Context:
         if len(order) != self.n:
             raise ValueError("order must have n entries")
         _check(self._lib.hicmi_rank_matrix(self._h, _ptr(order)))
+
+    def presort_state(self):
+        """(state, tied_rows) of the last rank_matrix.  state 0: it sorted every row itself; 1: it re-addressed the
+        rows sorted beside the nn-chain and sorted `tied_rows` rows (those holding equal similarities) again;
+        2: more than half of the rows hold equal similarities, the pre-sort was discarded (hicmi_presort_state)."""
+        st = ctypes.c_int(0)
+        tied = c_i64(0)
+        _check(self._lib.hicmi_presort_state(self._h, ctypes.byref(st), ctypes.byref(tied)))
+        return st.value, int(tied.value)
 
     def rank_rows(self, row0=0, nrows=None, inverse=False):
         nrows = self.n - row0 if nrows is None else nrows

@@ -41,10 +41,12 @@ namespace hicmi { int set_error(int code, const char* msg) { return fail(code, "
     } while (0)
 
 enum Family { F_ROW_SUMS, F_BUILD_W, F_NNCHAIN, F_SORT, F_RANK_INVERT, F_CUT_COUNT, F_HYPER_FLAGS, F_P2_SELECT,
-              F_P2_TOTAL, F_P2_SCORE, F_P2_EXACT, F_P2_INSERT, F_P2_WINDOW_G, F_P2_WINDOW_DELTA, F_PLOT, F_COUNT };
+              F_P2_TOTAL, F_P2_SCORE, F_P2_EXACT, F_P2_INSERT, F_P2_WINDOW_G, F_P2_WINDOW_DELTA, F_PLOT, F_PRESORT, F_RANK_RELABEL,
+              F_RANK_TIED, F_COUNT };
 static const char* kFamilyNames[F_COUNT] = {"row_sums", "build_w", "nnchain", "sort_rows", "rank_invert",
                                             "cut_count", "hyper_flags", "p2_select", "p2_total", "p2_score",
-                                            "p2_score_exact", "p2_score_insert", "p2_window_G", "p2_window_delta", "plot"};
+                                            "p2_score_exact", "p2_score_insert", "p2_window_G", "p2_window_delta", "plot",
+                                            "presort_rows", "rank_relabel", "rank_rows_tied"};
 
 constexpr int kBaseSlabs = 256;                        // partial sums of the closed-form BASE term (one slab per workgroup)
 
@@ -71,6 +73,16 @@ struct hicmi_ctx {
     uint16_t *dR = nullptr, *dRank = nullptr; int64_t ldr = 0; int64_t r_rows = 0;
     void* d_sort_scratch = nullptr; size_t sort_scratch_cap = 0;
     bool have_rank = false;
+    // pre-sort: the rank rows in storage labels, computed on a second stream while the nn-chain runs (hicmi_upgma)
+    hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint16_t* dRankS = nullptr; int64_t rank_s_rows = 0;
+    int32_t* d_ident = nullptr; int64_t ident_cap = 0;
+    unsigned char* d_ties = nullptr; int64_t ties_cap = 0;   // [count of flagged rows, 16 bytes][one flag per storage row]
+    uint16_t* d_tie_bits = nullptr; int64_t tie_bits_rows = 0, ld_bits = 0;   // per storage row: "same key as the element before"
+    int32_t* d_row_list = nullptr; int64_t row_list_cap = 0;
+    int64_t presort_tied_rows = 0;                        // ... and how many rows it re-sorted because they hold equal keys
+    int presort_used = 0;                                 // last hicmi_rank_matrix: 0 sorted itself, 1 relabelled the pre-sort, 2 pre-sort discarded (ties)
+    int64_t presort_n = 0;                                // > 0: dRankS holds the rows of the current n x n matrix
     // cut scan
     int32_t* d_x = nullptr; uint8_t* d_sig = nullptr; int64_t x_cap = 0;
     int64_t cached_start = -1;
@@ -128,21 +140,21 @@ namespace {
 hipError_t sync_stream(hicmi_ctx* c);
 
 struct Timed {
-    hicmi_ctx* c; int fam; hipEvent_t a = nullptr, b = nullptr;
-    Timed(hicmi_ctx* ctx, int f, double algo_bytes) : c(ctx), fam(f)
+    hicmi_ctx* c; int fam; hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
+    Timed(hicmi_ctx* ctx, int f, double algo_bytes, hipStream_t on_stream = nullptr) : c(ctx), fam(f), st(on_stream ? on_stream : ctx->stream)
     {
         c->launches[f]++; c->bytes[f] += algo_bytes;
         if (!on()) return;
         a = grab(); b = grab();
-        hipEventRecord(a, c->stream);
+        hipEventRecord(a, st);
     }
     // Event pairs around the hundreds of small launches of the scans and of Part 2 cost about 10 ms per 16k map;
     // mode 2 keeps them for the families that are launched a handful of times (the dominant kernel is one of them).
-    bool on() const { return c->timing == 1 || (c->timing == 2 && fam <= F_RANK_INVERT); }
+    bool on() const { return c->timing == 1 || (c->timing == 2 && (fam <= F_RANK_INVERT || fam >= F_PRESORT)); }
     ~Timed()
     {
         if (!on()) return;
-        hipEventRecord(b, c->stream);
+        hipEventRecord(b, st);
         c->regions.push_back({fam, a, b});
     }
     hipEvent_t grab()
@@ -156,6 +168,7 @@ int resolve_timing(hicmi_ctx* c)
 {
     if (c->regions.empty()) return HICMI_OK;
     HIPCHK(sync_stream(c));
+    if (c->stream2) HIPCHK(hipStreamSynchronize(c->stream2));
     for (auto& r : c->regions) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) c->ms[r.fam] += ms;
@@ -239,6 +252,8 @@ void drop_matrix_state(hicmi_ctx* c)
     c->dC = nullptr; c->own_c = false; c->n = 0; c->ldc = 0;
     free_dev(c->d_np); free_dev(c->d_seq); c->d_np = c->d_seq = nullptr; c->have_sums = false;
     c->have_rank = false; c->cached_start = -1; c->n2 = 0;
+    if (c->presort_n && c->stream2) (void)hipStreamSynchronize(c->stream2);    // the pre-sort reads the matrix being dropped
+    c->presort_n = 0;
 }
 
 int alloc_sums(hicmi_ctx* c)
@@ -304,6 +319,10 @@ int hicmi_destroy(hicmi_ctx* c)
     drop_matrix_state(c);
     free_dev(c->dW); free_dev(c->dW2); free_dev(c->d_size); free_dev(c->d_chain); free_dev(c->d_status); free_dev(c->d_zraw);
     free_dev(c->d_order); free_dev(c->dR); free_dev(c->dRank); free_dev(c->d_sort_scratch);
+    free_dev(c->dRankS); free_dev(c->d_ident); free_dev(c->d_ties); free_dev(c->d_row_list); free_dev(c->d_tie_bits);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     free_dev(c->d_x); free_dev(c->d_sig); free_dev(c->d_tmp);
     free_dev(c->dM2); free_dev(c->d_sel); free_dev(c->d_H); free_dev(c->d_perms); free_dev(c->d_scores);
     free_dev(c->d_partial); free_dev(c->d_T);
@@ -395,6 +414,8 @@ int hicmi_set_row_shard(hicmi_ctx* c, int64_t first, int64_t stride)
     if (!c || stride < 1 || first < 0 || first >= stride) return fail(HICMI_EINVAL, "row shard needs 0 <= first < stride");
     c->shard_first = first; c->shard_stride = stride;
     c->have_rank = false; c->cached_start = -1;
+    if (c->presort_n && c->stream2) (void)hipStreamSynchronize(c->stream2);
+    c->presort_n = 0;
     return HICMI_OK;
 }
 
@@ -408,6 +429,8 @@ int hicmi_set_row_sums(hicmi_ctx* c, const double* np_sum, const double* seq_sum
     rc = upload(c, c->d_seq, seq_sum, sizeof(double) * (size_t)c->n);
     if (rc) return rc;
     HIPCHK(sync_stream(c));
+    if (c->presort_n && c->stream2) HIPCHK(hipStreamSynchronize(c->stream2));
+    c->presort_n = 0;                                      // the similarity keys depend on the sums
     c->have_sums = true;
     return HICMI_OK;
 }
@@ -537,6 +560,101 @@ int hicmi_leaf_order(const double* Z, int64_t n, int32_t* leaves)
     return out == n ? HICMI_OK : fail(HICMI_ESTATE, "malformed linkage (%lld leaves of %lld)", (long long)out, (long long)n);
 }
 
+// Buffers of the rank matrix: dRank (result), d_order ([order][inverse]), dR (argsort rows of the bitonic path), scratch.
+static int ensure_rank_buffers(hicmi_ctx* c, int64_t n, int64_t ldr, bool bitonic)
+{
+    if (c->r_rows < n || c->ldr != ldr || !c->dRank) {
+        free_dev(c->dR); free_dev(c->dRank); free_dev(c->d_order); c->dR = c->dRank = nullptr; c->d_order = nullptr;
+        HIPCHK(hipMalloc((void**)&c->dRank, sizeof(uint16_t) * (size_t)n * (size_t)ldr));
+        HIPCHK(hipMalloc((void**)&c->d_order, sizeof(int32_t) * 2 * (size_t)n));       // [order][inverse order]
+        c->ldr = ldr; c->r_rows = n;
+    }
+    if (bitonic && !c->dR) HIPCHK(hipMalloc((void**)&c->dR, sizeof(uint16_t) * (size_t)n * (size_t)ldr));
+    size_t need = bitonic ? sort_scratch_bytes((int)n) : sort_radix_scratch_bytes((int)n);
+    if (need > c->sort_scratch_cap) {
+        free_dev(c->d_sort_scratch); c->d_sort_scratch = nullptr; c->sort_scratch_cap = 0;
+        HIPCHK(hipMalloc(&c->d_sort_scratch, need));
+        c->sort_scratch_cap = need;
+    }
+    return HICMI_OK;
+}
+
+// The pre-sort.  The nn-chain keeps 8 of the 256 CUs busy for 60 % of Part 1, and the row sort that follows it needs the
+// chain's result only for two things: the numbering of rows and columns (the leaf order) and the order of EQUAL
+// similarities inside a row.  A row without equal similarities has the same sorted sequence under any numbering, so its
+// rank row in leaf labels is the rank row in storage labels re-addressed: rank[a][b] = rank_s[order[a]][order[b]].
+// While the chain runs on the main stream, a second low-priority stream therefore sorts every row in storage labels
+// (same kernel, identity order, on at most 224 CUs so that the chain's workgroups and its flush kernels always find a
+// free one) and notes which rows hold equal keys, and where; hicmi_rank_matrix then only relabels (k_rank_relabel, ~0.5 ms
+// at 16k), and finishes the rows with equal keys (sparse maps, fp32 contacts: possibly all of them) with a sort of
+// 32-bit (run, leaf position) keys - k_sort_tied.hip.  HICMI_NO_PRESORT=1 disables.
+static int start_presort(hicmi_ctx* c)
+{
+    const bool off = getenv("HICMI_NO_PRESORT") != nullptr || getenv("HICMI_SORT_RADIX") != nullptr
+                     || getenv("HICMI_SORT_LDS") != nullptr;
+    const char* from = getenv("HICMI_PRESORT_FROM");               // (tests lower it; below ~2000 bins the sort is 0.3 ms)
+    const int64_t n = c->n;
+    c->presort_used = 0;
+    if (off || c->shard_stride != 1 || n < (from ? atoll(from) : 2048)) return HICMI_OK;
+    if (c->presort_n == n) return HICMI_OK;                       // same matrix, same sums: still valid
+    const int64_t ldr = (n + 63) & ~(int64_t)63;
+    int rc = ensure_rank_buffers(c, n, ldr, true);
+    if (rc) return rc;
+    if (!c->stream2) {
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));         // lo = least urgent
+        HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
+    }
+    if (!c->ev_fork) {
+        HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    if (c->ties_cap < n) {
+        free_dev(c->d_ties); c->d_ties = nullptr;
+        HIPCHK(hipMalloc((void**)&c->d_ties, 16 + (size_t)n));
+        c->ties_cap = n;
+    }
+    const int64_t ld_bits = std::max<int64_t>(sort_padded_size((int)n), 16) / 16;
+    if (c->tie_bits_rows < n || c->ld_bits != ld_bits) {
+        free_dev(c->d_tie_bits); c->d_tie_bits = nullptr;
+        HIPCHK(hipMalloc((void**)&c->d_tie_bits, sizeof(uint16_t) * (size_t)n * (size_t)ld_bits));
+        c->tie_bits_rows = n; c->ld_bits = ld_bits;
+    }
+    if (c->rank_s_rows < n || !c->dRankS) {
+        free_dev(c->dRankS); c->dRankS = nullptr;
+        HIPCHK(hipMalloc((void**)&c->dRankS, sizeof(uint16_t) * (size_t)n * (size_t)ldr));
+        c->rank_s_rows = n;
+    }
+    if (c->ident_cap < n) {
+        free_dev(c->d_ident); c->d_ident = nullptr;
+        HIPCHK(hipMalloc((void**)&c->d_ident, sizeof(int32_t) * (size_t)n));
+        std::vector<int32_t> id((size_t)n);
+        for (int64_t i = 0; i < n; i++) id[(size_t)i] = (int32_t)i;
+        int rc_up = upload(c, c->d_ident, id.data(), sizeof(int32_t) * (size_t)n);
+        if (rc_up) return rc_up;
+        c->ident_cap = n;
+    }
+    HIPCHK(hipEventRecord(c->ev_fork, c->stream));                // sums and identity are in place
+    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    HIPCHK(hipMemsetAsync(c->d_ties, 0, 16 + (size_t)n, c->stream2));
+    {
+        Timed t(c, F_PRESORT, (8.0 + 2.0 + 2.0 + 2.0) * (double)n * (double)n, c->stream2);
+        SortExtras x;
+        x.tie_count = reinterpret_cast<unsigned*>(c->d_ties); x.tie_flag = c->d_ties + 16;
+        x.tie_limit = (unsigned)n;                                 // (never gives up: tied rows are finished by k_rank_rows_tied)
+        x.tie_bits = c->d_tie_bits; x.ld_bits = ld_bits;
+        x.max_workgroups = 224;
+        launch_sort_rows(c->dC, c->ldc, c->d_ident, c->d_ident, c->d_np, c->d_seq, (int)n, c->d_sort_scratch, c->dR, ldr, 0, 1,
+                         c->stream2, x);
+        launch_rank_invert(c->dR, c->dRankS, ldr, (int)n, 0, 1, c->stream2);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+    c->presort_n = n;
+    c->have_rank = false;                                          // dR is being rewritten
+    return HICMI_OK;
+}
+
 int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
 {
     if (!c || !leaves_out) return fail(HICMI_EINVAL, "bad arguments");
@@ -564,6 +682,8 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         launch_build_w(c->dC, c->ldc, c->d_np, (int)n, c->dW, ldw, c->stream);
     }
     HIPCHK(hipGetLastError());
+    rc = start_presort(c);                                         // beside the chain, on the second stream
+    if (rc) return rc;
     // The nn-chain.  Algorithmic bytes: 8 B x (sum over row scans of the live columns + 3 x sum over merges
     // of the live columns), with the scans counted by the kernels themselves (a scan the neighbour cache answers moves
     // nothing); the merge term is 3 * 8 * sum_{k=0}^{n-2} (n - k).
@@ -663,19 +783,10 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
     // 15.7 / 87 / 581 ms against 11.7 / 50.6 / 236 ms): 18 passes x 7 workgroup barriers and random 4-byte LDS scatters
     // cost more than the 105 register-resident stages.  Kept as the second implementation the large-map tests compare with.
     const bool bitonic = getenv("HICMI_SORT_RADIX") == nullptr;
-    if (c->r_rows < n || c->ldr != ldr || !c->dRank) {
-        free_dev(c->dR); free_dev(c->dRank); free_dev(c->d_order); c->dR = c->dRank = nullptr; c->d_order = nullptr;
-        HIPCHK(hipMalloc((void**)&c->dRank, sizeof(uint16_t) * (size_t)n * (size_t)ldr));
-        HIPCHK(hipMalloc((void**)&c->d_order, sizeof(int32_t) * 2 * (size_t)n));       // [order][inverse order]
-        c->ldr = ldr; c->r_rows = n;
-    }
-    if (bitonic && !c->dR) HIPCHK(hipMalloc((void**)&c->dR, sizeof(uint16_t) * (size_t)n * (size_t)ldr));
-    size_t need = bitonic ? sort_scratch_bytes((int)n) : sort_radix_scratch_bytes((int)n);
-    if (need > c->sort_scratch_cap) {
-        free_dev(c->d_sort_scratch); c->d_sort_scratch = nullptr; c->sort_scratch_cap = 0;
-        HIPCHK(hipMalloc(&c->d_sort_scratch, need));
-        c->sort_scratch_cap = need;
-    }
+    if (c->presort_n != n) c->presort_used = 0;
+    if (c->presort_n && c->stream2) HIPCHK(hipStreamSynchronize(c->stream2));   // (the buffers below are the pre-sort's too)
+    rc = ensure_rank_buffers(c, n, ldr, bitonic);
+    if (rc) return rc;
     {
         std::vector<int32_t> both((size_t)(2 * n));
         for (int64_t i = 0; i < n; i++) { both[(size_t)i] = order[i]; both[(size_t)(n + order[i])] = (int32_t)i; }
@@ -683,6 +794,65 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
         if (rc_up) return rc_up;
     }
     const double share = 1.0 / (double)c->shard_stride;             // this shard's rows only
+    if (c->presort_n == n && c->shard_stride == 1 && bitonic) {
+        // rows sorted in storage labels while the nn-chain ran (start_presort): re-addressed by the leaf order; rows that
+        // hold equal keys get the order inside their runs from k_rank_rows_tied
+        std::vector<unsigned char> ties(16 + (size_t)n);
+        int rc_dl = download(c, ties.data(), c->d_ties, ties.size());
+        if (rc_dl) return rc_dl;
+        unsigned n_tied = 0;
+        memcpy(&n_tied, ties.data(), sizeof(n_tied));
+        // HICMI_PRESORT_TIES=resort: the rows with equal keys go through the full 64-bit sort again (the first version of
+        // this path, kept as the A/B for k_rank_rows_tied); it gives the pre-sort up when more than half of the rows do
+        const bool resort = getenv("HICMI_PRESORT_TIES") != nullptr && !strcmp(getenv("HICMI_PRESORT_TIES"), "resort");
+        c->presort_used = (resort && n_tied > (unsigned)(n / 2)) ? 2 : 1;
+        c->presort_tied_rows = (int64_t)n_tied;
+        if (c->presort_used == 1) {
+            // rows (in leaf numbering) whose storage row holds equal keys: the order inside their runs of equal keys
+            // depends on the leaf labels
+            std::vector<int32_t> again;
+            for (int64_t a = 0; a < n && n_tied; a++)
+                if (ties[16 + (size_t)order[a]]) again.push_back((int32_t)a);
+            if ((int64_t)again.size() < n) {
+                Timed t(c, F_RANK_RELABEL, (2.0 + 2.0) * (double)n * (double)(n - (int64_t)again.size()));
+                launch_rank_relabel(c->dRankS, c->dRank, ldr, (int)n, c->d_order, 0, 1, c->stream);
+            }
+            HIPCHK(hipGetLastError());
+            if (!again.empty()) {
+                if (c->row_list_cap < n) {
+                    free_dev(c->d_row_list); c->d_row_list = nullptr;
+                    HIPCHK(hipMalloc((void**)&c->d_row_list, sizeof(int32_t) * (size_t)n));
+                    c->row_list_cap = n;
+                }
+                int rc_up = upload(c, c->d_row_list, again.data(), sizeof(int32_t) * again.size());
+                if (rc_up) return rc_up;
+                const double part = (double)again.size() / (double)n;
+                if (resort) {
+                    c->presort_n = 0;                              // dR (the storage-label argsort rows) is overwritten
+                    SortExtras x;
+                    x.row_list = c->d_row_list; x.n_list = (int)again.size();
+                    {
+                        Timed t(c, F_SORT, (8.0 + 2.0) * (double)n * (double)n * part);
+                        launch_sort_rows(c->dC, c->ldc, c->d_order, c->d_order + n, c->d_np, c->d_seq, (int)n, c->d_sort_scratch,
+                                         c->dR, ldr, 0, 1, c->stream, x);
+                    }
+                    HIPCHK(hipGetLastError());
+                    Timed t(c, F_RANK_INVERT, (2.0 + 2.0) * (double)n * (double)n * part);
+                    launch_rank_invert(c->dR, c->dRank, ldr, (int)n, 0, 1, c->stream, c->d_row_list, (int)again.size());
+                } else {
+                    Timed t(c, F_RANK_TIED, (2.0 + 2.0) * (double)n * (double)n * part);
+                    launch_rank_rows_tied(c->dR, c->d_tie_bits, c->ld_bits, c->d_order, c->d_order + n, (int)n, c->d_row_list,
+                                          (int)again.size(), c->dRank, ldr, c->stream);
+                }
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(sync_stream(c));
+            c->have_rank = true;
+            c->cached_start = -1;
+            return HICMI_OK;
+        }
+    }
+    c->presort_n = 0;                                               // (dR is overwritten below)
     if (!bitonic) {
         Timed t(c, F_SORT, (8.0 + 2.0) * (double)n * (double)n * share);
         launch_rank_rows_radix(c->dC, c->ldc, c->d_order, c->d_order + n, c->d_np, c->d_seq, (int)n, c->d_sort_scratch, c->dRank,
@@ -701,6 +871,14 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
     HIPCHK(sync_stream(c));
     c->have_rank = true;
     c->cached_start = -1;
+    return HICMI_OK;
+}
+
+int hicmi_presort_state(hicmi_ctx* c, int* state_out, int64_t* tied_rows_out)
+{
+    if (!c || !state_out) return fail(HICMI_EINVAL, "bad arguments");
+    *state_out = c->presort_used;
+    if (tied_rows_out) *tied_rows_out = c->presort_used ? c->presort_tied_rows : 0;
     return HICMI_OK;
 }
 

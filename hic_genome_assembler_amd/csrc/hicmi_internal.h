@@ -140,14 +140,28 @@ void launch_hyper_flags(const int32_t* x, int nrows, int mode, int L_fixed, int6
 int  sort_padded_size(int n);                 // power of two >= n
 int  sort_workgroups(int n);                  // persistent workgroups the sort kernel wants
 size_t sort_scratch_bytes(int n);             // device scratch (keys + indices) for all workgroups
+struct SortExtras {                        // optional modes of launch_sort_rows (register-blocked bitonic kernel only)
+    const int32_t* row_list = nullptr; int n_list = 0;        // sort exactly these rows (instead of the row shard)
+    uint8_t* tie_flag = nullptr; unsigned* tie_count = nullptr; unsigned tie_limit = 0;   // flag rows holding equal keys
+    uint16_t* tie_bits = nullptr; int64_t ld_bits = 0;        // ... and which sorted elements repeat the key before them
+    int max_workgroups = 0;                                    // cap on the grid (0: the default)
+};
 void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const int32_t* inv, const double* np_sum,
                       const double* seq_sum, int n, void* scratch, uint16_t* R, int64_t ldr, int row_first, int row_stride,
-                      hipStream_t s);
+                      hipStream_t s, const SortExtras& x = SortExtras());
+// Rank rows of rows that hold equal keys, from the storage-label sort + its tie bits (k_sort_tied.hip).
+void launch_rank_rows_tied(const uint16_t* R_storage, const uint16_t* tie_bits, int64_t ld_bits, const int32_t* order,
+                           const int32_t* inv, int n, const int32_t* row_list, int n_list, uint16_t* rank, int64_t ldr,
+                           hipStream_t s);
+// rank[a][b] = rank_storage[order[a]][order[b]] (rows without equal keys; see k_sort.hip)
+void launch_rank_relabel(const uint16_t* rank_storage, uint16_t* rank, int64_t ldr, int n, const int32_t* order, int row_first,
+                         int row_stride, hipStream_t s);
 size_t sort_radix_scratch_bytes(int n);
 void launch_rank_rows_radix(const double* C, int64_t ldc, const int32_t* order, const int32_t* inv, const double* np_sum,
                             const double* seq_sum, int n, void* scratch, uint16_t* rank, int64_t ldr, int row_first,
                             int row_stride, hipStream_t s);   // LSD radix: writes the rank rows directly
-void launch_rank_invert(const uint16_t* R, uint16_t* rank, int64_t ldr, int n, int row_first, int row_stride, hipStream_t s);
+void launch_rank_invert(const uint16_t* R, uint16_t* rank, int64_t ldr, int n, int row_first, int row_stride, hipStream_t s,
+                        const int32_t* row_list = nullptr, int n_list = 0);
 void launch_similarity_row(const double* C, int64_t ldc, const int32_t* order, const double* np_sum,
                            const double* seq_sum, int n, int row, double* out, hipStream_t s);
 

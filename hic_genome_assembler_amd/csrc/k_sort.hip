@@ -246,10 +246,39 @@ __device__ __forceinline__ void rb_store_reversed(uint16_t* __restrict__ out, in
     }
 }
 
+// Equal keys on two ADJACENT elements of the sorted row (real cells only): the order of such a pair is decided by the
+// column labels, everything else in the row by the values alone.  Bit q of the lane's word says "ascending element
+// e0 + q has the key of element e0 + q - 1"; the lane compares its 16 elements with each other and its first with the
+// previous lane's last (through xk); `carry` (LDS) holds the last key of the previous tile of a long row.  The words go
+// to bits[e0 / 16] (k_rank_rows_tied reads them); returns whether the row has any such pair.
+__device__ __forceinline__ bool rb_row_tie_bits(const uint64_t (&K)[RB_E], int tid, int e0, int n, bool first_tile, uint64_t* xk,
+                                                uint16_t* __restrict__ bits)
+{
+    __shared__ uint64_t s_carry;                            // (xk is rewritten by the next tile's exchange stages)
+    uint32_t w = 0;
+#pragma unroll
+    for (int q = 1; q < RB_E; q++) w |= (uint32_t)((K[q] == K[q - 1]) && (e0 + q < n)) << q;
+    xk[tid] = K[RB_E - 1];
+    const uint64_t carried = s_carry;                       // written after the barriers of the previous call
+    __syncthreads();
+    const uint64_t before = tid > 0 ? xk[tid - 1] : carried;
+    if ((tid > 0 || !first_tile) && before == K[0] && e0 < n) w |= 1u;
+    if (tid == RB_T - 1) s_carry = K[RB_E - 1];
+    if (e0 < n) bits[e0 / RB_E] = (uint16_t)w;
+    return __syncthreads_or(w != 0) != 0;
+}
+
+// TIES: the kernel also flags the rows that hold equal keys (tie_flag[row] = 1, *tie_count = how many so far), writes
+// the "same key as the element before" bits of every row (tie_bits, ld_bits 16-bit words per row) and gives up once
+// more than tie_limit rows are flagged (the pre-sort of api.hip: start_presort uses tie_limit = n, i.e. never).
+// row_list != nullptr: sort rows row_list[0 .. n_list) instead of row_first, row_first + row_stride, ...
+template <bool TIES>
 __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
     const double* __restrict__ C, int64_t ldc, const int32_t* __restrict__ order, const double* __restrict__ np_sum,
     const double* __restrict__ seq_sum, int n, int P, uint64_t* __restrict__ skeys, uint16_t* __restrict__ sidx,
-    uint16_t* __restrict__ R, int64_t ldr, const int32_t* __restrict__ inv, int row_first, int row_stride)
+    uint16_t* __restrict__ R, int64_t ldr, const int32_t* __restrict__ inv, int row_first, int row_stride,
+    const int32_t* __restrict__ row_list, int n_list, uint8_t* __restrict__ tie_flag, unsigned* __restrict__ tie_count,
+    unsigned tie_limit, uint16_t* __restrict__ tie_bits, int64_t ld_bits)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* xk = reinterpret_cast<uint64_t*>(smem);                                   // (RB_E / 2) x RB_T keys
@@ -263,11 +292,17 @@ __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
     uint64_t K[RB_E];
     uint32_t I[RB_E];
 
-    for (int row = row_first + blockIdx.x * row_stride; row < n; row += gridDim.x * row_stride) {   // this shard's rows
+    const int n_rows = row_list ? n_list : (n - row_first + row_stride - 1) / row_stride;          // this shard's rows
+    for (int it = blockIdx.x; it < n_rows; it += gridDim.x) {
+        const int row = row_list ? row_list[it] : row_first + it * row_stride;
         // the lane index is re-read through an opaque statement per row: otherwise lane-dependent addresses are hoisted out
         // of the row loop, spilled, and re-loaded / re-stored in every row (1.2 GB of scratch writes per 16k map)
         int tid = tid0;
         asm volatile("" : "+v"(tid));
+        if (TIES) {
+            if (__syncthreads_or(tid == 0 && *(volatile unsigned*)tie_count > tie_limit)) break;
+        }
+        bool row_tie = false;
         const int pa = order[row];
         const double sig = np_sum[pa], rs = seq_sum[pa];
         const double* __restrict__ crow = C + (int64_t)pa * ldc;
@@ -299,6 +334,7 @@ __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
                 int tid2 = tid;                             // (output addresses formed here, not before the sort and spilled)
                 asm volatile("" : "+v"(tid2));
                 if (live) rb_store_reversed(out, n, RB_E * tid2, I);
+                if (TIES) row_tie = rb_row_tie_bits(K, tid, RB_E * tid, live ? n : 0, true, xk, tie_bits + (int64_t)row * ld_bits);
             } else {
 #pragma unroll
                 for (int q = 0; q < RB_E; q++) { gk[base + RB_E * tid + q] = K[q]; gi[base + RB_E * tid + q] = (uint16_t)I[q]; }
@@ -323,6 +359,7 @@ __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
                     int tid2 = tid;
                     asm volatile("" : "+v"(tid2));
                     rb_store_reversed(out, n, base + RB_E * tid2, I);
+                    if (TIES) row_tie |= rb_row_tie_bits(K, tid, base + RB_E * tid, n, t == 0, xk, tie_bits + (int64_t)row * ld_bits);
                 } else {
 #pragma unroll
                     for (int q = 0; q < RB_E; q++) { gk[base + RB_E * tid + q] = K[q]; gi[base + RB_E * tid + q] = (uint16_t)I[q]; }
@@ -330,6 +367,7 @@ __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
             }
         }
         __syncthreads();
+        if (TIES && row_tie && tid == 0) { tie_flag[row] = 1; atomicAdd(tie_count, 1u); }
     }
 }
 
@@ -574,19 +612,32 @@ void launch_rank_rows_radix(const double* C, int64_t ldc, const int32_t* order, 
 
 void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const int32_t* inv, const double* np_sum,
                       const double* seq_sum, int n, void* scratch, uint16_t* R, int64_t ldr, int row_first, int row_stride,
-                      hipStream_t s)
+                      hipStream_t s, const SortExtras& x)
 {
+    unsigned* const tie_rows = x.tie_count;
+    const int max_workgroups = x.max_workgroups;
     static const bool lds_network = getenv("HICMI_SORT_LDS") != nullptr;      // A/B switch: the LDS-resident network
-    if (!lds_network) {
+    if (!lds_network || tie_rows || x.row_list) {
         int P = sort_padded_size(n);
         if (P < RB_E) P = RB_E;
-        const int wgs = sort_workgroups(n);
+        int wgs = sort_workgroups(n);
+        if (max_workgroups > 0 && wgs > max_workgroups) wgs = max_workgroups;
+        if (x.row_list && wgs > x.n_list) wgs = x.n_list;
+        if (wgs < 1) return;
         uint64_t* skeys = reinterpret_cast<uint64_t*>(scratch);
         uint16_t* sidx = reinterpret_cast<uint16_t*>(skeys + (size_t)wgs * (size_t)P);
         const size_t lds = (size_t)(RB_E / 2) * RB_T * (sizeof(uint64_t) + sizeof(uint16_t));
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_rows_rb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_sort_rows_rb, dim3(wgs), dim3(RB_T), lds, s, C, ldc, order, np_sum, seq_sum, n, P, skeys,
-                           sidx, R, ldr, inv, row_first, row_stride);
+        if (tie_rows) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_rows_rb<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_sort_rows_rb<true>, dim3(wgs), dim3(RB_T), lds, s, C, ldc, order, np_sum, seq_sum, n, P, skeys,
+                               sidx, R, ldr, inv, row_first, row_stride, x.row_list, x.n_list, x.tie_flag, x.tie_count, x.tie_limit,
+                               x.tie_bits, x.ld_bits);
+            return;
+        }
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_rows_rb<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_sort_rows_rb<false>, dim3(wgs), dim3(RB_T), lds, s, C, ldc, order, np_sum, seq_sum, n, P, skeys,
+                           sidx, R, ldr, inv, row_first, row_stride, x.row_list, x.n_list, (uint8_t*)nullptr, (unsigned*)nullptr, 0u,
+                           (uint16_t*)nullptr, (int64_t)0);
         return;
     }
     const int P = sort_padded_size(n);
@@ -602,11 +653,14 @@ void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const 
 
 // rank[row][R[row][k]] = k : scatter inside LDS (2 bytes per bin), coalesced in and out.
 __global__ __launch_bounds__(1024) void k_rank_invert(const uint16_t* __restrict__ R, uint16_t* __restrict__ rank,
-                                                      int64_t ldr, int n, int row_first, int row_stride)
+                                                      int64_t ldr, int n, int row_first, int row_stride,
+                                                      const int32_t* __restrict__ row_list, int n_list)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* inv = reinterpret_cast<uint16_t*>(smem);
-    for (int row = row_first + blockIdx.x * row_stride; row < n; row += gridDim.x * row_stride) {
+    const int n_rows = row_list ? n_list : (n - row_first + row_stride - 1) / row_stride;
+    for (int it = blockIdx.x; it < n_rows; it += gridDim.x) {
+        const int row = row_list ? row_list[it] : row_first + it * row_stride;
         const uint16_t* __restrict__ r = R + (int64_t)row * ldr;
         for (int k = threadIdx.x; k < n; k += 1024) inv[r[k]] = (uint16_t)k;
         __syncthreads();
@@ -616,12 +670,53 @@ __global__ __launch_bounds__(1024) void k_rank_invert(const uint16_t* __restrict
     }
 }
 
-void launch_rank_invert(const uint16_t* R, uint16_t* rank, int64_t ldr, int n, int row_first, int row_stride, hipStream_t s)
+void launch_rank_invert(const uint16_t* R, uint16_t* rank, int64_t ldr, int n, int row_first, int row_stride, hipStream_t s,
+                        const int32_t* row_list, int n_list)
 {
+    if (row_list && n_list < 1) return;
     size_t lds = ((size_t)n * sizeof(uint16_t) + 15) & ~(size_t)15;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_invert), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int grid = n < 1024 ? n : 1024;
-    hipLaunchKernelGGL(k_rank_invert, dim3(grid), dim3(1024), lds, s, R, rank, ldr, n, row_first, row_stride);
+    if (row_list && grid > n_list) grid = n_list;
+    hipLaunchKernelGGL(k_rank_invert, dim3(grid), dim3(1024), lds, s, R, rank, ldr, n, row_first, row_stride, row_list, n_list);
+}
+
+// rank[a][b] = rank_storage[order[a]][order[b]]: the rank rows computed in STORAGE labels (rows and columns numbered as the
+// matrix is stored) re-addressed by the leaf order.  Valid for rows without equal keys - there the position of a column
+// depends on the values only.  One workgroup per row: the source row into LDS (coalesced), gathered through the order.
+__global__ __launch_bounds__(1024) void k_rank_relabel(const uint16_t* __restrict__ rank_storage, uint16_t* __restrict__ rank,
+                                                       int64_t ldr, int n, const int32_t* __restrict__ order, int row_first,
+                                                       int row_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* src = reinterpret_cast<uint16_t*>(smem);
+    const int n8 = (n + 7) & ~7;                            // ldr is a multiple of 64: whole 16-byte groups stay inside the row
+    for (int a = row_first + blockIdx.x * row_stride; a < n; a += gridDim.x * row_stride) {
+        const uint4* __restrict__ in = reinterpret_cast<const uint4*>(rank_storage + (int64_t)order[a] * ldr);
+        for (int g = threadIdx.x; g < n8 / 8; g += 1024) reinterpret_cast<uint4*>(src)[g] = in[g];
+        __syncthreads();
+        uint4* __restrict__ o = reinterpret_cast<uint4*>(rank + (int64_t)a * ldr);
+        for (int g = threadIdx.x; g < n8 / 8; g += 1024) {
+            uint32_t w[4];
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                const int b0 = 8 * g + 2 * h, b1 = b0 + 1;
+                const uint32_t lo = b0 < n ? src[order[b0]] : 0u, hi = b1 < n ? src[order[b1]] : 0u;
+                w[h] = lo | (hi << 16);
+            }
+            o[g] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        __syncthreads();
+    }
+}
+
+void launch_rank_relabel(const uint16_t* rank_storage, uint16_t* rank, int64_t ldr, int n, const int32_t* order, int row_first,
+                         int row_stride, hipStream_t s)
+{
+    size_t lds = ((size_t)((n + 7) & ~7) * sizeof(uint16_t) + 15) & ~(size_t)15;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_relabel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int grid = n < 2048 ? n : 2048;
+    hipLaunchKernelGGL(k_rank_relabel, dim3(grid), dim3(1024), lds, s, rank_storage, rank, ldr, n, order, row_first, row_stride);
 }
 
 __global__ __launch_bounds__(256) void k_similarity_row(const double* __restrict__ C, int64_t ldc,

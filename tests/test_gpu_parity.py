@@ -943,3 +943,98 @@ def test_row_sort_across_tiles_with_ties(hic, monkeypatch, n, sorter):
             inv = ctx.rank_rows(r, 1, inverse=True)[0].astype(np.int64)
             assert np.array_equal(inv[want], np.arange(n)), r
             assert len(np.unique(sim)) < n // 10                               # the ties are really there
+
+
+@pytest.mark.parametrize("n,tie_at,ties_by", [
+    (3000, None, "runs"), (3000, 7, "runs"), (3000, 15, "runs"), (3000, 1023, "runs"), (3000, 15, "resort"),
+    (2500, "many", "runs"), (2500, "many", "resort"), (2500, "most", "runs"), (2500, "most", "resort"),
+    (20000, None, "runs"), (20000, 16383, "runs")])
+def test_rows_sorted_beside_the_chain_equal_rows_sorted_after_it(hic, monkeypatch, n, tie_at, ties_by):
+    """hicmi_upgma sorts every row in storage numbering on a second stream while the nn-chain runs, and hicmi_rank_matrix
+    re-addresses those rows by the leaf order; in a row holding equal similarities the order inside each run of equal
+    values depends on the labels and is made afterwards (k_rank_rows_tied; HICMI_PRESORT_TIES=resort: by sorting those
+    rows again in full, giving the pre-sort up when most rows need it).  Either way the rank rows must be those of the
+    plain path (HICMI_NO_PRESORT=1) - which the other tests pin to the oracle.  tie_at = p: ONE pair of equal values in
+    one row, at ascending positions p, p + 1 of the sorted row - inside a lane's 16 elements (7), across two lanes (15),
+    across two waves (1023), across two 16384-element tiles (16383)."""
+    monkeypatch.setenv("HICMI_PRESORT_FROM", "1000")
+    if ties_by == "resort":
+        monkeypatch.setenv("HICMI_PRESORT_TIES", "resort")
+    rng = np.random.default_rng(17)
+    if tie_at == "most":
+        c = rng.integers(0, 40, size=(n, n)).astype(np.float64)
+        c = np.triu(c) + np.triu(c, 1).T
+    else:
+        c = rng.random((n, n)) + 0.01
+        c = np.triu(c) + np.triu(c, 1).T
+    tied = []
+    if isinstance(tie_at, int):
+        r = 5
+        by_value = np.argsort(c[r], kind="stable")
+        ja, jb = int(by_value[tie_at]), int(by_value[tie_at + 1])
+        c[r, ja] = c[ja, r] = c[r, jb]
+        tied = [r]
+    elif tie_at == "many":
+        tied = list(range(100, 600))
+        for r in tied:
+            j1, j2 = 700 + (r % 900), 1700 + (r % 700)
+            c[r, j2] = c[j2, r] = c[r, j1]
+    order_kind = "leaves" if n != 3000 or tie_at in (None, 15) else "random"
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(c)
+        leaves, _z = ctx.upgma()
+        order = leaves if order_kind == "leaves" else rng.permutation(n).astype(np.int32)
+        ctx.rank_matrix(order)
+        state, n_tied = ctx.presort_state()
+        rows = list(range(n)) if n <= 3000 else [0, 1, 5, 4097, n - 1] + [int(np.where(order == r)[0][0]) for r in tied]
+        got = np.stack([ctx.rank_rows(a, 1, inverse=True)[0] for a in rows]) if n > 3000 else ctx.rank_rows(inverse=True)
+        monkeypatch.setenv("HICMI_NO_PRESORT", "1")
+        ctx.set_contacts(c)
+        leaves2, _z = ctx.upgma()
+        assert np.array_equal(leaves, leaves2)
+        ctx.rank_matrix(order)
+        assert ctx.presort_state() == (0, 0)
+        want = np.stack([ctx.rank_rows(a, 1, inverse=True)[0] for a in rows]) if n > 3000 else ctx.rank_rows(inverse=True)
+        if tied:                                            # the tie is really there, and in the expected row
+            a = int(np.where(order == tied[0])[0][0])
+            sim = ctx.similarity_row(a)
+            assert len(np.unique(sim)) == n - 1
+    assert np.array_equal(got, want)
+    if tie_at == "most":
+        assert (state, n_tied) == ((2, n) if ties_by == "resort" else (1, n))
+    else:
+        assert state == 1
+        # (two close contacts can round to the same similarity: ~n/1000 more rows than the planted ones may be flagged)
+        assert len(tied) <= n_tied <= len(tied) + 3 + n // 400
+
+
+@pytest.mark.parametrize("n", [20000, 40000])              # 32 / 64 elements per lane in k_rank_rows_tied
+def test_long_rows_full_of_equal_similarities(hic, monkeypatch, n):
+    """Quantised contacts (every row is mostly runs of equal similarities) at row lengths where k_rank_rows_tied keeps 32
+    and 64 keys per lane: sampled rows against numpy's stable argsort of the same similarity row, and against the path
+    without the pre-sort."""
+    import torch
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(11)
+    c = torch.randint(0, 40, (n, n), generator=g, device="cuda:0").to(torch.float64)
+    c = torch.triu(c) + torch.triu(c, 1).T
+    c.fill_diagonal_(3.0)
+    torch.cuda.synchronize()
+    rows = (0, 3, 8191, 16384, n - 1)
+    with hic.Context(0) as ctx:
+        ctx.set_contacts_device(c.data_ptr(), n, keepalive=c)
+        leaves, _z = ctx.upgma()
+        ctx.rank_matrix(leaves)
+        assert ctx.presort_state() == (1, n)
+        got = {r: ctx.rank_rows(r, 1, inverse=True)[0].astype(np.int64) for r in rows}
+        for r in rows:
+            sim = ctx.similarity_row(r)
+            want = np.argsort(sim, kind="stable")[::-1]
+            assert np.array_equal(got[r][want], np.arange(n)), r
+        monkeypatch.setenv("HICMI_NO_PRESORT", "1")
+        ctx.set_contacts_device(c.data_ptr(), n, keepalive=c)
+        ctx.upgma()
+        ctx.rank_matrix(leaves)
+        assert ctx.presort_state() == (0, 0)
+        for r in rows:
+            assert np.array_equal(ctx.rank_rows(r, 1, inverse=True)[0].astype(np.int64), got[r]), r
