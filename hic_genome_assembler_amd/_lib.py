@@ -44,6 +44,9 @@ SIGNATURES = {
     "hicmi_get_similarity_row": (ctypes.c_int, [_vp, c_i64, _vp]),
     "hicmi_cut_scan": (ctypes.c_int, [_vp, c_i64, c_i64, c_dbl, _vp, _vp]),
     "hicmi_filter_scan": (ctypes.c_int, [_vp, c_i64, c_i64, c_i64, c_i64, c_dbl, _vp, _vp]),
+    "hicmi_first_pass_cuts": (ctypes.c_int, [_vp, c_i64, c_i64, c_dbl, _vp, c_i64, _vp, _vp, c_i64, _vp]),
+    "hicmi_filter_cuts": (ctypes.c_int, [_vp, _vp, c_i64, c_dbl, _vp, c_i64, _vp, _vp]),
+    "hicmi_hypergeom_decide": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i64, c_dbl]),
     "hicmi_hypergeom_sf": (c_dbl, [c_i64, c_i64, c_i64, c_i64]),
     "hicmi_selftest_division": (ctypes.c_int, [_vp, ctypes.c_uint64, c_i64, ctypes.POINTER(ctypes.c_uint64)]),
     "hicmi_label_linkage": (ctypes.c_int, [_vp, c_i64, _vp]),
@@ -153,6 +156,11 @@ def scan_valid_pairs(path, names, pairs, threads: int = 0):
 def hypergeom_sf(x, M, n, N) -> float:
     """hyper_geom(x, M, n, N) of scaffoldToChromosomes.py:352-368, evaluated by libhicmi's host code."""
     return float(load().hicmi_hypergeom_sf(int(x), int(M), int(n), int(N)))
+
+
+def hypergeom_decide(x, M, n, N, psig) -> int:
+    """1 / 0 / -1: hyper_geom(x, M, n, N) < psig, >= psig, NaN - the early-exit comparison the scan kernels make."""
+    return int(load().hicmi_hypergeom_decide(int(x), int(M), int(n), int(N), float(psig)))
 
 
 class Context:
@@ -312,6 +320,24 @@ class Context:
         x = np.empty(n_rows, np.int32) if want_x else None
         _check(self._lib.hicmi_filter_scan(self._h, start, c, n_rows, M, psig, _ptr(x), _ptr(sig)))
         return (sig, x) if want_x else sig
+
+    def first_pass_cuts(self, min_size, stop_ind, psig):
+        """pre_process_all_matrix_breakpoints' loop on the device (hicmi_first_pass_cuts): (cuts, [(M before, M after), ...])."""
+        cuts = np.empty(self.n, np.int32)
+        mlog = np.empty((self.n, 2), np.int32)
+        nc, nl = c_i64(0), c_i64(0)
+        _check(self._lib.hicmi_first_pass_cuts(self._h, int(min_size), int(stop_ind), float(psig), _ptr(cuts), self.n,
+                                               ctypes.byref(nc), _ptr(mlog), self.n, ctypes.byref(nl)))
+        return [int(v) for v in cuts[:nc.value]], [(int(a), int(b)) for a, b in mlog[:nl.value]]
+
+    def filter_cuts(self, cuts, psig):
+        """filter_noisy_breakpoints' loops on the device (hicmi_filter_cuts): (sorted kept cuts, warnings)."""
+        cuts = np.ascontiguousarray(cuts, dtype=np.int32)
+        out = np.empty(self.n, np.int32)
+        m, warned = c_i64(0), c_i64(0)
+        _check(self._lib.hicmi_filter_cuts(self._h, _ptr(cuts), len(cuts), float(psig), _ptr(out), self.n,
+                                           ctypes.byref(m), ctypes.byref(warned)))
+        return [int(v) for v in out[:m.value]], int(warned.value)
 
     # ---- Part 2
     def p2_select(self, sel):

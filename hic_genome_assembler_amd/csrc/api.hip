@@ -11,6 +11,7 @@
 #include <numeric>
 #include <string>
 #include <unordered_map>
+#include <functional>
 #include <vector>
 
 #include "../../include/hicmi.h"
@@ -85,6 +86,7 @@ struct hicmi_ctx {
     int64_t presort_n = 0;                                // > 0: dRankS holds the rows of the current n x n matrix
     // cut scan
     int32_t* d_x = nullptr; uint8_t* d_sig = nullptr; int64_t x_cap = 0;
+    unsigned char* d_scan_prog = nullptr; int64_t scan_prog_cap = 0;     // device-driven scan loops: state record + lists
     int64_t cached_start = -1;
     double* d_tmp = nullptr; int64_t tmp_cap = 0;
     // part 2
@@ -323,7 +325,7 @@ int hicmi_destroy(hicmi_ctx* c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    free_dev(c->d_x); free_dev(c->d_sig); free_dev(c->d_tmp);
+    free_dev(c->d_x); free_dev(c->d_sig); free_dev(c->d_tmp); free_dev(c->d_scan_prog);
     free_dev(c->dM2); free_dev(c->d_sel); free_dev(c->d_H); free_dev(c->d_perms); free_dev(c->d_scores);
     free_dev(c->d_partial); free_dev(c->d_T);
     free_dev(c->d_scaf_start); free_dev(c->d_scaf_len); free_dev(c->d_arr_packed);
@@ -1008,6 +1010,136 @@ int hicmi_filter_scan(hicmi_ctx* c, int64_t start, int64_t cut, int64_t n_rows, 
 }
 
 double hicmi_hypergeom_sf(int64_t x, int64_t M, int64_t n, int64_t N) { return hypergeom_sf_ge(x, M, n, N); }
+int hicmi_hypergeom_decide(int64_t x, int64_t M, int64_t n, int64_t N, double psig) { return hypergeom_decide(x, M, n, N, psig); }
+
+// ---- the two scan loops with their control flow on the device (k_part1_scan.hip) -------------------------------------
+// One allocation: [ScanState, 256 B][cuts n][M log 2n][alt n][seg 3n][seg_x n] int32, then [filt n][prev n] bytes.
+static int ensure_scan_program(hicmi_ctx* c)
+{
+    if (c->scan_prog_cap >= c->n && c->d_scan_prog) return HICMI_OK;
+    free_dev(c->d_scan_prog); c->d_scan_prog = nullptr; c->scan_prog_cap = 0;
+    HIPCHK(hipMalloc((void**)&c->d_scan_prog, 256 + sizeof(int32_t) * 8 * (size_t)c->n + 2 * (size_t)c->n + 64));
+    c->scan_prog_cap = c->n;
+    return HICMI_OK;
+}
+
+struct ScanProgram {
+    ScanState* st; int32_t *cuts, *mlog, *alt, *seg, *seg_x; uint8_t *filt, *prev;
+    explicit ScanProgram(hicmi_ctx* c)
+    {
+        unsigned char* b = c->d_scan_prog;
+        const size_t n = (size_t)c->scan_prog_cap;
+        st = reinterpret_cast<ScanState*>(b);
+        cuts = reinterpret_cast<int32_t*>(b + 256);
+        mlog = cuts + n; alt = mlog + 2 * n; seg = alt + n; seg_x = seg + 3 * n;
+        filt = reinterpret_cast<uint8_t*>(seg_x + n); prev = filt + n;
+    }
+};
+
+// Batches of scans until the device says the loop has ended.  `pairs` launches per batch: the record is read once per batch.
+static int run_scan_program(hicmi_ctx* c, ScanState& h, const ScanProgram& p, int64_t max_scans,
+                            const std::function<void(int)>& enqueue)
+{
+    int rc = upload(c, p.st, &h, sizeof(h));
+    if (rc) return rc;
+    const int pairs = 32;
+    int64_t batches = 0;
+    for (int64_t issued = 0; ; issued += pairs) {
+        if (issued > max_scans + pairs) return fail(HICMI_ESTATE, "scan loop did not end after %lld scans", (long long)issued);
+        {
+            Timed t(c, F_CUT_COUNT, 0.0);
+            enqueue(pairs);
+        }
+        HIPCHK(hipGetLastError());
+        batches++;
+        rc = download(c, &h, p.st, sizeof(h));
+        if (rc) return rc;
+        if (h.done) break;
+    }
+    c->launches[F_CUT_COUNT] += (int64_t)h.scans - batches;       // the family is reported per scan
+    c->launches[F_HYPER_FLAGS] += (int64_t)h.scans;               // (the decisions ride in the same launches)
+    c->bytes[F_CUT_COUNT] += (double)h.bytes;
+    c->cached_start = -1;                                          // d_x was reused
+    return HICMI_OK;
+}
+
+int hicmi_first_pass_cuts(hicmi_ctx* c, int64_t min_size, int64_t stop_ind, double psig, int32_t* cuts_out, int64_t cuts_cap,
+                          int64_t* n_cuts_out, int32_t* m_log_out, int64_t log_cap, int64_t* n_log_out)
+{
+    if (!c || !cuts_out || !n_cuts_out || !n_log_out || (log_cap > 0 && !m_log_out)) return fail(HICMI_EINVAL, "bad arguments");
+    if (!c->have_rank) return fail(HICMI_EINVAL, "hicmi_rank_matrix has not run");
+    if (c->shard_stride != 1) return fail(HICMI_EINVAL, "the device-driven scan loops need the whole rank matrix (no row shard)");
+    if (min_size < 1) return fail(HICMI_EINVAL, "min_size must be >= 1");
+    const int64_t n = c->n;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_scan_buffers(c);
+    if (rc) return rc;
+    rc = ensure_scan_program(c);
+    if (rc) return rc;
+    ScanProgram p(c);
+    ScanState h;
+    memset(&h, 0, sizeof(h));
+    h.mode = 0; h.start = 0; h.M = n; h.recount = 1;
+    h.min_size = (int)std::min<int64_t>(min_size, n + 1); h.stop_ind = (int)std::min<int64_t>(stop_ind, INT32_MAX);
+    const int lcap = (int)n;                                       // pairs that fit the device log
+    rc = run_scan_program(c, h, p, 6 * n, [&](int pairs) {
+        launch_first_pass_pairs(c->dRank, c->ldr, (int)n, p.st, c->d_x, c->d_sig, psig, p.cuts, p.mlog, lcap, pairs, c->stream);
+    });
+    if (rc) return rc;
+    if (h.n_cuts > cuts_cap) return fail(HICMI_EINVAL, "%d cuts do not fit cuts_cap", h.n_cuts);
+    if (h.n_log > lcap || h.n_log > log_cap) return fail(HICMI_EINVAL, "%d M changes do not fit the log", h.n_log);
+    if (h.n_cuts) { rc = download(c, cuts_out, p.cuts, sizeof(int32_t) * (size_t)h.n_cuts); if (rc) return rc; }
+    if (h.n_log) { rc = download(c, m_log_out, p.mlog, sizeof(int32_t) * 2 * (size_t)h.n_log); if (rc) return rc; }
+    *n_cuts_out = h.n_cuts; *n_log_out = h.n_log;
+    return HICMI_OK;
+}
+
+int hicmi_filter_cuts(hicmi_ctx* c, const int32_t* cuts_in, int64_t n_in, double psig, int32_t* cuts_out, int64_t cuts_cap,
+                      int64_t* n_out, int64_t* warned_out)
+{
+    if (!c || !cuts_in || !cuts_out || !n_out || n_in < 1) return fail(HICMI_EINVAL, "bad arguments");
+    if (!c->have_rank) return fail(HICMI_EINVAL, "hicmi_rank_matrix has not run");
+    if (c->shard_stride != 1) return fail(HICMI_EINVAL, "the device-driven scan loops need the whole rank matrix (no row shard)");
+    const int64_t n = c->n;
+    if (n_in > n) return fail(HICMI_EINVAL, "more cuts than rows");
+    for (int64_t i = 0; i < n_in; i++)
+        if (cuts_in[i] < 0 || cuts_in[i] >= n || (i && cuts_in[i] <= cuts_in[i - 1]))
+            return fail(HICMI_EINVAL, "cuts must be ascending indices in [0, n)");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_scan_buffers(c);
+    if (rc) return rc;
+    rc = ensure_scan_program(c);
+    if (rc) return rc;
+    ScanProgram p(c);
+    rc = upload(c, p.alt, cuts_in, sizeof(int32_t) * (size_t)n_in);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(p.filt, 0, 2 * (size_t)c->scan_prog_cap, c->stream));      // filtered = {}, prev_filtered = {}
+    ScanState h;
+    memset(&h, 0, sizeof(h));
+    h.mode = 1; h.start = 0; h.M = n; h.recount = 1;
+    h.MD = (int)(n / 5);                                           // MD = int(n / 5)  (S2C:575)
+    h.n_alt = (int)n_in; h.f_max_rounds = (int)std::min<int64_t>(10 * n_in, INT32_MAX);   // S2C:577
+    h.cut = cuts_in[0];
+    h.n_rows = (int)std::min<int64_t>(n, (int64_t)h.MD + 1);
+    const int max_rows = (int)std::min<int64_t>(n, (int64_t)h.MD + 1);
+    // every pass over the candidates runs at most 10 * n_in rounds of at most n_in scans; the passes end when the set
+    // of kept cuts repeats - bounded here far above anything a map produces
+    const int64_t max_scans = std::min<int64_t>((int64_t)4000000, 20 * n_in * n_in * 10 + 1000);
+    rc = run_scan_program(c, h, p, max_scans, [&](int pairs) {
+        launch_filter_pairs(c->dRank, c->ldr, (int)n, max_rows, p.st, c->d_x, c->d_sig, psig, p.alt, p.filt, p.prev, p.seg,
+                            p.seg_x, pairs, c->stream);
+    });
+    if (rc) return rc;
+    std::vector<uint8_t> kept((size_t)n);
+    rc = download(c, kept.data(), p.filt, (size_t)n);
+    if (rc) return rc;
+    int64_t m = 0;
+    for (int64_t e = 0; e < n; e++)
+        if (kept[(size_t)e]) { if (m >= cuts_cap) return fail(HICMI_EINVAL, "filtered cuts do not fit cuts_cap"); cuts_out[m++] = (int32_t)e; }
+    *n_out = m;
+    if (warned_out) *warned_out = h.f_warned;
+    return HICMI_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------
 int hicmi_p2_select(hicmi_ctx* c, const int32_t* sel, int64_t n)

@@ -136,6 +136,24 @@ void launch_cut_count(const uint16_t* rank, int64_t ldr, int row0, int nrows, in
 void launch_hyper_flags(const int32_t* x, int nrows, int mode, int L_fixed, int64_t M, double psig, uint8_t* sig,
                         int own_first, int own_step, hipStream_t s);
 
+// k_part1_scan.hip: the cut-scan loops with their control flow on the device.  One record in device memory carries the
+// arguments of the next scan and the loop state; the host reads it back once per batch of scans.
+struct ScanState {
+    int done;              // the loop has ended: later launches return at once
+    int mode;              // 0 first pass (S2C:413-551), 1 filter (S2C:553-727)
+    int start, cut, n_rows, recount;
+    long long M;
+    int min_size, stop_ind, loop_count, n_cuts, n_log, scans;          // first pass
+    int MD, n_alt, alt_off, f_i, f_keep_from, f_noise, f_round, f_max_rounds, f_warned;   // filter
+    int pad;
+    unsigned long long bytes;                                           // rank bytes the scans' queries cover
+};
+void launch_first_pass_pairs(const uint16_t* rank, int64_t ldr, int n, ScanState* st, int32_t* x, uint8_t* sig, double psig,
+                             int32_t* cuts, int32_t* mlog, int log_cap, int pairs, hipStream_t s);
+void launch_filter_pairs(const uint16_t* rank, int64_t ldr, int n, int max_rows, ScanState* st, int32_t* x, uint8_t* sig,
+                         double psig, int32_t* alt, uint8_t* filt, uint8_t* prev, int32_t* seg, int32_t* seg_x, int pairs,
+                         hipStream_t s);
+
 // k_sort.hip
 int  sort_padded_size(int n);                 // power of two >= n
 int  sort_workgroups(int n);                  // persistent workgroups the sort kernel wants

@@ -152,11 +152,13 @@ HICMI_HD double hypergeom_sf_ge(int64_t x, int64_t M, int64_t n, int64_t N)
 // hypergeom_decide returns 1 if hyper_geom(x, M, n, N) < psig, 0 if >= psig, -1 if it is NaN - the same decision as
 // comparing hypergeom_sf_ge's value, but the tail sum stops as soon as the comparison is settled:
 //   * the partial sums are monotone, so a partial sum beyond the threshold settles it exactly;
-//   * once the term ratio is <= 1/2 the rest of the tail is <= the current term, so when even that cannot reach the
-//     threshold (with a 1e-9 relative margin) it is settled the other way.  Inside the margin the loop just goes on
-//     to the full sum, i.e. to hypergeom_sf_ge's own value.
-// A row well inside a cluster (x far above the mode) needs a few terms instead of ~50, a row at the mode (p ~ 0.5)
-// a handful instead of hundreds.
+//   * the pmf is log-concave: walking away from the mode the term ratio only falls, so with the current ratio r < 1
+//     the rest of the tail is below the geometric series term * r / (1 - r); when even that cannot reach the threshold
+//     (with a 1e-9 relative margin) it is settled the other way.  Written without the division:
+//     rest < gap  <=>  term * r < gap * (1 - r).  Inside the margin the loop just goes on to the full sum, i.e. to
+//     hypergeom_sf_ge's own value.
+// A row well inside a cluster (x far above the mode) needs a few terms instead of ~50, a row near the mode (p ~ 0.5)
+// tens instead of hundreds - and the slowest row of a scan is what a scan waits for.
 HICMI_HD int hypergeom_decide(int64_t x, int64_t M, int64_t n, int64_t N, double psig)
 {
     if (!(M > 0 && n >= 0 && N >= 0 && n <= M && N <= M)) return -1;
@@ -180,7 +182,7 @@ HICMI_HD int hypergeom_decide(int64_t x, int64_t M, int64_t n, int64_t N, double
             if (s1 == sum) break;
             sum = s1;
             if (!(sum < psig)) return 0;                          // only grows from here
-            if (ratio <= 0.5 && sum + term < below) return 1;     // the rest of the tail is <= term
+            if (ratio < 1.0 && term * ratio < (below - sum) * (1.0 - ratio)) return 1;   // the rest cannot reach psig
         }
         return (sum > 1.0 ? 1.0 : sum) < psig ? 1 : 0;
     }

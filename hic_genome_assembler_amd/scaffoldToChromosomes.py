@@ -214,6 +214,15 @@ def get_sliding_window_distance_metrics(input_array, window_size, global_index=0
     return [int(v) for v in scores], int(window_size), best
 
 
+def _device_scan_loops(ctx):
+    """The scan loops run with their control flow on the device when the context has the whole rank matrix (one GPU)
+    and offers the entry points; HICMI_HOST_SCANS=1 keeps the per-scan host loops (the A/B, and what a row shard uses)."""
+    if os.environ.get("HICMI_HOST_SCANS"):
+        return False
+    _first, world = getattr(ctx, "shard", (0, 1))
+    return world == 1 and hasattr(ctx, "first_pass_cuts") and hasattr(ctx, "filter_cuts")
+
+
 def find_matrix_pvalue_breakpoints(argsorted_mat: RankMatrix, start, min_size, world_size, psig=.05):
     """S2C:413-511 for one ``start``.  Counts and significance flags come from the GPU
     (hicmi_cut_scan); the >= 90 % rule that shrinks M (S2C:473-483) and the window scan run here.
@@ -252,6 +261,13 @@ def pre_process_all_matrix_breakpoints(argsorted_mat: RankMatrix, min_size=5, mi
     cinds = []
     if min_frac == 1:
         return cinds
+    if _device_scan_loops(argsorted_mat.ctx) and min_size >= 1:
+        # the same loop with its decisions on the device (hicmi_first_pass_cuts): one host round trip per batch of scans
+        cinds, m_changes = argsorted_mat.ctx.first_pass_cuts(min_size, stop_ind, .05)
+        for morg, m in m_changes:
+            print("- M value (world_size) changed to dynamic {} --> {}".format(morg, m))
+        print("- Breakpoints found {}".format(len(cinds)))
+        return cinds
     while True:
         _vals, pre_cut_inds = find_matrix_pvalue_breakpoints(argsorted_mat, ind, min_size, mat_size - ind, psig=.05)
         if len(pre_cut_inds) == 0:
@@ -272,6 +288,14 @@ def filter_noisy_breakpoints(argsorted_mat: RankMatrix, original_inds, psig=.05)
     ctx = argsorted_mat.ctx
     first, world = getattr(ctx, "shard", (0, 1))
     n = len(argsorted_mat)
+    ascending = all(b > a for a, b in zip(original_inds, original_inds[1:]))
+    if _device_scan_loops(ctx) and ascending and 0 <= original_inds[0] and original_inds[-1] < n:
+        out, warned = ctx.filter_cuts(original_inds, psig)          # the loops below, on the device (hicmi_filter_cuts)
+        for _ in range(warned):
+            print("- WARNING - Maximum number of rounds {} exceeded".format(10 * len(original_inds)))
+        print("- Original cut indices {}".format(list(original_inds)))
+        print("- Filtered cut indices {}".format(out))
+        return out
     MD = int(n / 5)
     MAX_ROUNDS = 10 * len(original_inds)
     altered = [int(v) for v in original_inds]

@@ -133,9 +133,30 @@ int hicmi_cut_scan(hicmi_ctx *ctx, int64_t start, int64_t M, double psig, int32_
 int hicmi_filter_scan(hicmi_ctx *ctx, int64_t start, int64_t c, int64_t n_rows, int64_t M, double psig,
                       int32_t *x_out, uint8_t *sig_out);
 
+/* The two scan loops as a whole, with their control flow on the device: every scan's arguments come out of the previous
+ * scan's flags, so driven from the host (hicmi_cut_scan / hicmi_filter_scan in a Python loop) each of the ~230 scans of
+ * a 16k map pays a launch, a download and a decision on top of its few tens of microseconds of device work.  Here the
+ * decisions are kernels too (k_part1_scan.hip), the host enqueues scans in batches and reads one small record per batch.
+ * Not available on a row shard (the flags of every scan would have to be gathered): the per-scan calls remain for that.
+ *
+ * hicmi_first_pass_cuts = pre_process_all_matrix_breakpoints (S2C:513-551) with find_matrix_pvalue_breakpoints
+ * (S2C:413-511) inside: min_size >= 1; stop_ind = int(n - n * min_frac), computed by the caller; psig as the caller
+ * passes it (the reference passes the literal .05, S2C:535).  cuts_out: the cut indices in the order found.  m_log_out:
+ * pairs (M before, M after) of every "M value (world_size) changed" event (S2C:473-483), in order - the reference
+ * prints them.
+ * hicmi_filter_cuts = filter_noisy_breakpoints (S2C:553-727): cuts_in ascending; cuts_out = sorted(filtered);
+ * *warned_out = how many times the "maximum number of rounds" warning (S2C:592-595) was reached. */
+int hicmi_first_pass_cuts(hicmi_ctx *ctx, int64_t min_size, int64_t stop_ind, double psig, int32_t *cuts_out,
+                          int64_t cuts_cap, int64_t *n_cuts_out, int32_t *m_log_out, int64_t log_cap, int64_t *n_log_out);
+int hicmi_filter_cuts(hicmi_ctx *ctx, const int32_t *cuts_in, int64_t n_in, double psig, int32_t *cuts_out,
+                      int64_t cuts_cap, int64_t *n_out, int64_t *warned_out);
+
 /* hyper_geom (S2C:352-368) = scipy.stats.hypergeom.sf(x-1, M, n, N); NaN for invalid arguments.
  * Host-side scalar evaluation with the same code the kernels run. */
 double hicmi_hypergeom_sf(int64_t x, int64_t M, int64_t n, int64_t N);
+/* The comparison the scans make with it, as the kernels evaluate it (host build of the same routine, for tests):
+ * 1 if hyper_geom(x, M, n, N) < psig, 0 if >= psig, -1 if it is NaN - the tail sum stops as soon as that is settled. */
+int hicmi_hypergeom_decide(int64_t x, int64_t M, int64_t n, int64_t N, double psig);
 
 /* Host helpers that finish scipy's linkage: stable sort of raw merges by height + union-find
  * relabel, and the count-sorted leaf walk.  Exposed for tests. */

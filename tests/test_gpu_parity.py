@@ -1038,3 +1038,58 @@ def test_long_rows_full_of_equal_similarities(hic, monkeypatch, n):
         assert ctx.presort_state() == (0, 0)
         for r in rows:
             assert np.array_equal(ctx.rank_rows(r, 1, inverse=True)[0].astype(np.int64), got[r]), r
+
+
+def _scan_loops_both_ways(hic, c, monkeypatch, capsys, min_size, min_frac, psig, cuts_for_filter=None):
+    """pre_process_all_matrix_breakpoints and filter_noisy_breakpoints on one clustered map, with the loops' decisions on
+    the device (default) and on the host (HICMI_HOST_SCANS=1): cuts and printed messages of both."""
+    from hic_genome_assembler_amd import scaffoldToChromosomes as s2c
+    out = {}
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(c)
+        leaves, _z = ctx.upgma()
+        ctx.rank_matrix(leaves)
+        rm = s2c.RankMatrix(ctx)
+        for how in ("device", "host"):
+            if how == "host":
+                monkeypatch.setenv("HICMI_HOST_SCANS", "1")
+            else:
+                monkeypatch.delenv("HICMI_HOST_SCANS", raising=False)
+            capsys.readouterr()
+            cuts = s2c.pre_process_all_matrix_breakpoints(rm, min_size=min_size, min_frac=min_frac, psig=psig)
+            kept = s2c.filter_noisy_breakpoints(rm, cuts_for_filter if cuts_for_filter is not None else cuts, psig=psig)
+            out[how] = (cuts, kept, capsys.readouterr().out)
+    return out
+
+
+@pytest.mark.parametrize("name,min_size,min_frac", [("n160", 5, .05), ("n600", 5, .05), ("n600", 2, .05), ("n600", 9, .3),
+                                                    ("n500_sparse", 5, .05), ("n300_edges", 5, .05), ("n600", 1, .0)])
+def test_scan_loops_on_the_device_equal_the_host_loops(hic, monkeypatch, capsys, name, min_size, min_frac):
+    """hicmi_first_pass_cuts / hicmi_filter_cuts take the decisions of S2C:413-551 / 553-727 in kernels; the per-scan host
+    loops (which the golden pipelines pin to the reference) must give the same cuts and print the same lines."""
+    spec, meta, gold, lay, c = gc.load_case(name)
+    c = np.asarray(c, np.float64)
+    keep = c.sum(axis=1) != 0                                # (removeRows: n300_edges has empty rows)
+    c = np.ascontiguousarray(c[keep][:, keep])
+    both = _scan_loops_both_ways(hic, c, monkeypatch, capsys, min_size, min_frac, .05)
+    assert both["device"][0] == both["host"][0]
+    assert both["device"][1] == both["host"][1]
+    assert both["device"][2] == both["host"][2]
+    if min_size == 5 and min_frac == .05:
+        assert len(both["host"][0]) > 0                      # (the case does produce cuts)
+
+
+@pytest.mark.parametrize("n,seed", [(3000, 3), (8000, 4)])
+def test_scan_loops_on_the_device_synthetic_maps(hic, monkeypatch, capsys, n, seed):
+    """The same on synthetic maps with planted chromosomes (dozens of cuts, hundreds of scans), and with a candidate
+    list denser than anything the first pass produces (every 40th index): many rounds, restarts and merged cuts."""
+    from hic_genome_assembler_amd import synth
+    lay = synth.make_layout(n, seed=seed)
+    c = synth.dense_contacts(lay, seed=seed)
+    both = _scan_loops_both_ways(hic, c, monkeypatch, capsys, 5, .05, .05)
+    assert both["device"] == both["host"]
+    assert len(both["host"][0]) >= 5
+    dense = list(range(40, n - 40, 40))
+    both = _scan_loops_both_ways(hic, c, monkeypatch, capsys, 5, .05, .05, cuts_for_filter=dense)
+    assert both["device"] == both["host"]
+    assert 0 < len(both["host"][1]) < len(dense)

@@ -59,6 +59,36 @@ def test_host_hypergeom_matches_scipy(lib):
     assert lib.hypergeom_sf(0, 10, 4, 4) == 1.0 and lib.hypergeom_sf(5, 10, 4, 4) == 0.0
 
 
+def test_early_exit_hypergeom_decision_equals_the_full_sum(lib):
+    """The scan kernels only need `hyper_geom(...) < psig` and stop the tail sum as soon as that is settled (hyper.h:
+    hypergeom_decide, here in its host build): the decision must be that of the full sum and of SciPy - for draws on both
+    sides of the mode, for the two shapes the scans use (n = N = L; the filter's scalar tests n != N) and for thresholds
+    from tiny to almost 1."""
+    from scipy.stats import hypergeom
+    rng = np.random.default_rng(5)
+    n_near = 0
+    for it in range(6000):
+        M = int(rng.integers(1, 66000))
+        if it % 2:
+            n = N = int(rng.integers(1, M + 1))
+        else:
+            n = int(rng.integers(0, M + 1)); N = int(rng.integers(0, M + 1))
+        mean = n * N / M
+        sd = max(1.0, (mean * (1 - n / M) * (M - N) / max(M - 1, 1)) ** 0.5)
+        x = int(round(mean + rng.normal() * 2.5 * sd))
+        full = lib.hypergeom_sf(x, M, n, N)
+        ref = float(hypergeom.sf(x - 1, M, n, N))
+        for psig in (.05, 1e-6, .5, .95, 1e-300):
+            dec = lib.hypergeom_decide(x, M, n, N, psig)
+            assert dec == (1 if full < psig else 0), (x, M, n, N, psig, full)
+            if abs(ref - psig) > 1e-9 * psig:
+                assert dec == (1 if ref < psig else 0), (x, M, n, N, psig, ref)
+            n_near += abs(ref - psig) < .3 * psig
+    assert n_near > 300                                       # (the thresholds are really being approached)
+    assert lib.hypergeom_decide(1, 5, 6, 2, .05) == -1 and lib.hypergeom_decide(0, 10, 4, 4, .05) == 0
+    assert lib.hypergeom_decide(5, 10, 4, 4, .05) == 1
+
+
 def test_linkage_helpers_match_oracle(lib):
     import ctypes
     L = lib.load()
