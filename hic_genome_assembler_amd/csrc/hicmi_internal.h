@@ -154,6 +154,32 @@ void launch_filter_pairs(const uint16_t* rank, int64_t ldr, int n, int max_rows,
                          double psig, int32_t* alt, uint8_t* filt, uint8_t* prev, int32_t* seg, int32_t* seg_x, int pairs,
                          hipStream_t s);
 
+// The value lane ^ M holds, M a power of two below 64, without the LDS crossbar (ds_bpermute, which __shfl_xor compiles
+// to, issues at a fraction of the VALU rate and was what the bitonic networks' in-wave stages waited for): DPP quad
+// permutes and row mirrors inside a row of 16 lanes, gfx950's v_permlane16_swap / v_permlane32_swap across rows.
+#if defined(__HIPCC__)
+template <int M>
+__device__ __forceinline__ uint32_t xor_lane(uint32_t v, int lane)
+{
+    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);       // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) {
+        const int t = __builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true);                            // row_half_mirror: ^ 7
+        return (uint32_t)__builtin_amdgcn_mov_dpp(t, 0x1B, 0xf, 0xf, true);                               // quad_perm [3,2,1,0]: ^ 3
+    } else if constexpr (M == 8) {
+        const int t = __builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true);                            // row_mirror: ^ 15
+        return (uint32_t)__builtin_amdgcn_mov_dpp(t, 0x141, 0xf, 0xf, true);                              // ^ 7
+    } else if constexpr (M == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);     // odd rows of one copy <-> even rows of the other
+        return (lane & 16) ? r[0] : r[1];
+    } else {
+        static_assert(M == 32, "xor_lane: M must be 1, 2, 4, 8, 16 or 32");
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);     // upper half of one copy <-> lower half of the other
+        return (lane & 32) ? r[0] : r[1];
+    }
+}
+#endif
+
 // k_sort.hip
 int  sort_padded_size(int n);                 // power of two >= n
 int  sort_workgroups(int n);                  // persistent workgroups the sort kernel wants

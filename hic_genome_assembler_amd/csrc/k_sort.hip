@@ -179,18 +179,33 @@ __device__ __forceinline__ void rb_inreg_tail(uint64_t (&K)[RB_E], uint32_t (&I)
     }
 }
 
-// partner lane = lane ^ m inside the wave; the lane with the clear bit keeps the minima when ascending
-__device__ __forceinline__ void rb_shuffle_stage(uint64_t (&K)[RB_E], uint32_t (&I)[RB_E], int m, bool keep_min)
+// partner lane = lane ^ M inside the wave; the lane with the clear bit keeps the minima when ascending.  The partner's
+// (key, column) come through DPP / permlane swaps (xor_lane, hicmi_internal.h), not through the LDS crossbar.
+template <int M>
+__device__ __forceinline__ void rb_xor_stage(uint64_t (&K)[RB_E], uint32_t (&I)[RB_E], int lane, bool keep_min)
 {
 #pragma unroll
     for (int q = 0; q < RB_E; q++) {
-        const uint64_t ok = __shfl_xor(K[q], m, 64);
-        const uint32_t oi = __shfl_xor(I[q], m, 64);
+        const uint32_t ol = xor_lane<M>((uint32_t)K[q], lane), oh = xor_lane<M>((uint32_t)(K[q] >> 32), lane);
+        const uint64_t ok = ((uint64_t)oh << 32) | ol;
+        const uint32_t oi = xor_lane<M>(I[q], lane);
         const bool other_lt = RB_LT(ok, oi, K[q], I[q]);
         if (other_lt == keep_min) { K[q] = ok; I[q] = oi; }
         // four exchanges in flight at a time: with all sixteen hoisted the kernel needed 204 bytes of scratch per lane - spills
         // inside the stages, 1.7 GB of write traffic for a 0.5 GB result in the round-1 counters
         if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void rb_shuffle_stage(uint64_t (&K)[RB_E], uint32_t (&I)[RB_E], int lane, int m, bool keep_min)
+{
+    switch (m) {
+    case 1: rb_xor_stage<1>(K, I, lane, keep_min); break;
+    case 2: rb_xor_stage<2>(K, I, lane, keep_min); break;
+    case 4: rb_xor_stage<4>(K, I, lane, keep_min); break;
+    case 8: rb_xor_stage<8>(K, I, lane, keep_min); break;
+    case 16: rb_xor_stage<16>(K, I, lane, keep_min); break;
+    default: rb_xor_stage<32>(K, I, lane, keep_min); break;
     }
 }
 
@@ -223,7 +238,7 @@ __device__ __forceinline__ void rb_tile_stages(uint64_t (&K)[RB_E], uint32_t (&I
     for (int j = j_start; j >= RB_E; j >>= 1) {
         const int m = j / RB_E;
         const bool keep_min = ((tid & m) == 0) == asc;
-        if (m < 64) rb_shuffle_stage(K, I, m, keep_min);
+        if (m < 64) rb_shuffle_stage(K, I, tid, m, keep_min);
         else rb_lds_stage(K, I, tid, m, keep_min, xk, xi);
     }
     rb_inreg_tail(K, I, asc, j_start);

@@ -40,14 +40,28 @@ __device__ __forceinline__ void ck_inreg_tail(uint32_t (&K)[E], bool asc, int j_
     }
 }
 
-template <int E>
-__device__ __forceinline__ void ck_shuffle_stage(uint32_t (&K)[E], int m, bool keep_min)
+template <int E, int M>
+__device__ __forceinline__ void ck_xor_stage(uint32_t (&K)[E], int lane, bool keep_min)
 {
 #pragma unroll
     for (int q = 0; q < E; q++) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)K[q], m, 64);
+        const uint32_t o = xor_lane<M>(K[q], lane);
         const uint32_t lo = o < K[q] ? o : K[q], hi = o < K[q] ? K[q] : o;
         K[q] = keep_min ? lo : hi;
+    }
+}
+
+// partner lane = lane ^ m inside the wave (m = 1 .. 32)
+template <int E>
+__device__ __forceinline__ void ck_shuffle_stage(uint32_t (&K)[E], int lane, int m, bool keep_min)
+{
+    switch (m) {
+    case 1: ck_xor_stage<E, 1>(K, lane, keep_min); break;
+    case 2: ck_xor_stage<E, 2>(K, lane, keep_min); break;
+    case 4: ck_xor_stage<E, 4>(K, lane, keep_min); break;
+    case 8: ck_xor_stage<E, 8>(K, lane, keep_min); break;
+    case 16: ck_xor_stage<E, 16>(K, lane, keep_min); break;
+    default: ck_xor_stage<E, 32>(K, lane, keep_min); break;
     }
 }
 
@@ -151,7 +165,7 @@ __global__ __launch_bounds__(CK_T) void k_rank_rows_tied(
             for (int j = k >> 1; j >= E; j >>= 1) {
                 const int m = j / E;
                 const bool keep_min = ((tid & m) == 0) == asc;
-                if (m < 64) ck_shuffle_stage<E>(K, m, keep_min);
+                if (m < 64) ck_shuffle_stage<E>(K, tid, m, keep_min);
                 else ck_lds_stage<E>(K, tid, m, keep_min, xk);
             }
             ck_inreg_tail<E>(K, asc, E / 2);
