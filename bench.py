@@ -35,7 +35,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
-PMC_KERNELS = {"nnchain": ("hicmi::k_nn_epoch", ), "sort_rows": ("hicmi::k_sort_rows", ), "row_sums": ("hicmi::k_row_sums", ),
+PMC_KERNELS = {"nnchain": ("hicmi::k_nn_epoch", ), "sort_rows": ("hicmi::k_sort_rows_rb<false>", "hicmi::k_sort_rows_radix"),
+               "presort_rows": ("hicmi::k_sort_rows_rb<true>", ), "rank_relabel": ("hicmi::k_rank_relabel", ),
+               "rank_rows_tied": ("hicmi::k_rank_rows_tied", ), "row_sums": ("hicmi::k_row_sums", ),
                "build_w": ("hicmi::k_build_w", ), "rank_invert": ("hicmi::k_rank_invert", ), "cut_count": ("hicmi::k_cut", )}
 
 

@@ -597,7 +597,7 @@ static int start_presort(hicmi_ctx* c)
     const char* from = getenv("HICMI_PRESORT_FROM");               // (tests lower it; below ~2000 bins the sort is 0.3 ms)
     const int64_t n = c->n;
     c->presort_used = 0;
-    if (off || c->shard_stride != 1 || n < (from ? atoll(from) : 2048)) return HICMI_OK;
+    if (off || n < (from ? atoll(from) : 2048)) return HICMI_OK;     // (a row shard pre-sorts ALL rows: it is idle meanwhile)
     if (c->presort_n == n) return HICMI_OK;                       // same matrix, same sums: still valid
     const int64_t ldr = (n + 63) & ~(int64_t)63;
     int rc = ensure_rank_buffers(c, n, ldr, true);
@@ -796,7 +796,7 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
         if (rc_up) return rc_up;
     }
     const double share = 1.0 / (double)c->shard_stride;             // this shard's rows only
-    if (c->presort_n == n && c->shard_stride == 1 && bitonic) {
+    if (c->presort_n == n && bitonic) {
         // rows sorted in storage labels while the nn-chain ran (start_presort): re-addressed by the leaf order; rows that
         // hold equal keys get the order inside their runs from k_rank_rows_tied
         std::vector<unsigned char> ties(16 + (size_t)n);
@@ -812,12 +812,14 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
         if (c->presort_used == 1) {
             // rows (in leaf numbering) whose storage row holds equal keys: the order inside their runs of equal keys
             // depends on the leaf labels
-            std::vector<int32_t> again;
-            for (int64_t a = 0; a < n && n_tied; a++)
+            std::vector<int32_t> again;                            // (of this shard's rows)
+            const int64_t own = (n - c->shard_first + c->shard_stride - 1) / c->shard_stride;
+            for (int64_t a = c->shard_first; a < n && n_tied; a += c->shard_stride)
                 if (ties[16 + (size_t)order[a]]) again.push_back((int32_t)a);
-            if ((int64_t)again.size() < n) {
-                Timed t(c, F_RANK_RELABEL, (2.0 + 2.0) * (double)n * (double)(n - (int64_t)again.size()));
-                launch_rank_relabel(c->dRankS, c->dRank, ldr, (int)n, c->d_order, 0, 1, c->stream);
+            if ((int64_t)again.size() < own) {
+                Timed t(c, F_RANK_RELABEL, (2.0 + 2.0) * (double)n * (double)(own - (int64_t)again.size()));
+                launch_rank_relabel(c->dRankS, c->dRank, ldr, (int)n, c->d_order, (int)c->shard_first, (int)c->shard_stride,
+                                    c->stream);
             }
             HIPCHK(hipGetLastError());
             if (!again.empty()) {

@@ -110,8 +110,9 @@ int hicmi_rank_matrix(hicmi_ctx *ctx, const int32_t *order);
  * every row in STORAGE numbering: a row without equal similarities has the same sorted sequence under any numbering,
  * so hicmi_rank_matrix only re-addresses it by `order`; in a row that does hold equal similarities the order inside each
  * run of equal values depends on the labels, and is made afterwards by a cheaper sort of (run, label) keys.
- * *state_out: 0 = all rows sorted by hicmi_rank_matrix itself (no hicmi_upgma before it, a row shard, n < 2048 or
- * HICMI_NO_PRESORT=1), 1 = pre-sorted rows used, *tied_rows_out (may be NULL) of them held equal similarities,
+ * Under a row shard the pre-sort covers ALL rows (the GPU is idle during the replicated chain) and only the own rows are
+ * re-addressed.  *state_out: 0 = all rows sorted by hicmi_rank_matrix itself (no hicmi_upgma before it, n < 2048 or
+ * HICMI_NO_PRESORT=1), 1 = pre-sorted rows used, *tied_rows_out (may be NULL) of all rows held equal similarities,
  * 2 = pre-sort discarded (only with HICMI_PRESORT_TIES=resort, the A/B mode that re-sorts tied rows in full). */
 int hicmi_presort_state(hicmi_ctx *ctx, int *state_out, int64_t *tied_rows_out);
 /* Copy rows [row0, row0+nrows) of R (or of its inverse when inverse != 0) to the host as uint16. */

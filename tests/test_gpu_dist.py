@@ -21,7 +21,8 @@ def _worker(rank, world, port, tmp_root, name):
     import contextlib
     import io
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), HICMI_NO_PLOTS="1")
+                      MASTER_PORT=str(port), HICMI_NO_PLOTS="1",
+                      HICMI_PRESORT_FROM="200")           # (the pre-sort beside the chain also on these small maps)
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     import golden_cases as cases
     from hic_genome_assembler_amd import _lib, dist, orderGenome as p2, scaffoldToChromosomes as p1
@@ -45,7 +46,12 @@ def _worker(rank, world, port, tmp_root, name):
         seen["scans"] += 1
         seen["foreign_nonzero"] += int(np.count_nonzero(sig[rows % world != rank]))
         return sig
-    _lib.Context.cut_scan, _lib.Context.filter_scan = spy_cut, spy_filter
+    inner_rank = _lib.Context.rank_matrix
+
+    def spy_rank(self, order):
+        inner_rank(self, order)
+        seen["presort"] = self.presort_state()[0]
+    _lib.Context.cut_scan, _lib.Context.filter_scan, _lib.Context.rank_matrix = spy_cut, spy_filter, spy_rank
     tmp = os.path.join(tmp_root, "r%d" % rank)
     os.makedirs(tmp)
     spec = cases.load_case(name)[0]
@@ -68,6 +74,7 @@ def _worker(rank, world, port, tmp_root, name):
             adj.ctx.close()
     assert len(ordered) == len(chroms)
     assert seen["scans"] > 10 and seen["foreign_nonzero"] == 0    # this rank only ever flagged its own rows
+    assert seen["presort"] == 1                                   # all rows pre-sorted beside the chain, the own ones re-addressed
     part1 = {fn: open(f(fn)).read() for fn in ("dendrogramOrder.txt", "binGroups.txt", "assessment.txt", "chromosomeGroups.txt")}
     for fn, text in part1.items():
         assert text == cases.golden_text(name, fn), (rank, fn)   # every rank wrote the reference's Part 1 files
