@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_p2_base_partial(const double* __restric
     base_partial_body(M2, ld2, p, n_arr, H, n_tot, blockIdx.x, gridDim.x, partial + blockIdx.x);
 }
 
-static std::atomic<int> g_lds_base{0}, g_lds_straddle{0}, g_lds_cross{0}, g_lds_wdelta{0}, g_lds_wdelta1{0}, g_lds_wdelta_blk{0}, g_lds_wG{0}, g_lds_insb_base{0};
+static std::atomic<int> g_lds_base{0}, g_lds_straddle{0}, g_lds_cross{0}, g_lds_wdelta{0}, g_lds_wdelta1{0}, g_lds_wdelta_blk{0}, g_lds_wG{0}, g_lds_insb_base{0}, g_lds_insb_fast{0};
 
 // BASE as partial sums over row slabs: out[0..n_blocks)
 void launch_p2_base_partial(const double* M2, int64_t ld2, const int32_t* pos2sel, int n_arr, const double* H, int n_tot,
@@ -243,8 +243,13 @@ __global__ __launch_bounds__(256) void k_insb_base(const InsStep* __restrict__ s
 //       (k_insb_shortlist adds the rows of a scaffold in position order)
 //   workgroups after those: one per (gap, orientation), CROSS as in cross_body with 4 waves over the new bins.
 // partial layout per chromosome: [n_base_blocks BASE slabs][n_arr row values s(u)][2(S+1) CROSS terms]
-__global__ __launch_bounds__(256) void k_insb_fast(const InsStep* __restrict__ steps, int n_base_blocks, int n_row_blocks)
+//   in front of all those (the longest workgroups first): the BASE slabs of k_insb_base - independent of the rest
+//       (same inputs, a disjoint part of `partial`), so they ride in the same launch instead of in a launch of their
+//       own: one dependent launch fewer in each of the ~136 lock steps of a 16k map
+__global__ __launch_bounds__(256) void k_insb_fast(const InsStep* __restrict__ steps, int n_base_blocks, int n_row_blocks,
+                                                   int n_cross_blocks)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double s_w[4];
     const InsStep& d = steps[blockIdx.y];
     if (!d.active || d.st->fail >= 0) return;
@@ -253,8 +258,18 @@ __global__ __launch_bounds__(256) void k_insb_fast(const InsStep* __restrict__ s
     const int32_t* __restrict__ p = d.pos_cur;
     const int32_t* __restrict__ arr_pos = d.packed_cur + S;
     const double* __restrict__ H = d.H;
-    if ((int)blockIdx.x < n_row_blocks) {
-        const int u = blockIdx.x * 4 + wave;
+    const int n_base_here = (int)gridDim.x - n_row_blocks - n_cross_blocks;      // 0 when BASE has its own launch (A/B)
+    const int bx = (int)blockIdx.x - n_base_here;
+    if (bx < 0) {
+        const int slab = blockIdx.x;
+        int32_t* pl = reinterpret_cast<int32_t*>(smem);
+        for (int q = threadIdx.x; q < n_arr; q += 256) pl[q] = p[q];
+        __syncthreads();
+        base_partial_body(d.M2, d.ld2, pl, n_arr, H, n_arr + L, slab, n_base_blocks, d.partial + slab);
+        return;
+    }
+    if (bx < n_row_blocks) {
+        const int u = bx * 4 + wave;
         if (u >= n_arr) return;
         int below = 0;                                    // scaffold of position u: the last gap with arr_pos <= u
         for (int j = lane; j <= S; j += 64) below += arr_pos[j] <= u;
@@ -278,7 +293,7 @@ __global__ __launch_bounds__(256) void k_insb_fast(const InsStep* __restrict__ s
         if (lane == 0) d.partial[n_base_blocks + u] = acc;
         return;
     }
-    const int c = blockIdx.x - n_row_blocks;
+    const int c = bx - n_row_blocks;
     if (c >= 2 * (S + 1)) return;
     const int g = c >> 1, r = c & 1, P = arr_pos[g];
     const double hn = H[n_arr + L - 1];
@@ -303,11 +318,15 @@ __global__ __launch_bounds__(256) void k_insb_fast(const InsStep* __restrict__ s
 void launch_insb_fast(const InsStep* steps, int n_chrom, int max_S, int max_n_arr, int n_base_blocks, hipStream_t s)
 {
     const size_t lds = perm_lds_bytes(max_n_arr);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_insb_base), g_lds_insb_base, lds);
-    hipLaunchKernelGGL(k_insb_base, dim3(n_base_blocks, n_chrom), dim3(256), lds, s, steps, n_base_blocks);
-    const int n_row_blocks = (max_n_arr + 3) / 4;
-    hipLaunchKernelGGL(k_insb_fast, dim3(n_row_blocks + 2 * (max_S + 1), n_chrom), dim3(256), 0, s, steps, n_base_blocks,
-                       n_row_blocks);
+    const int n_row_blocks = (max_n_arr + 3) / 4, n_cross_blocks = 2 * (max_S + 1);
+    static const bool split = getenv("HICMI_P2_INSB_SPLIT") != nullptr;       // A/B: BASE as its own launch, as before
+    if (split) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_insb_base), g_lds_insb_base, lds);
+        hipLaunchKernelGGL(k_insb_base, dim3(n_base_blocks, n_chrom), dim3(256), lds, s, steps, n_base_blocks);
+    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_insb_fast), g_lds_insb_fast, lds);
+    hipLaunchKernelGGL(k_insb_fast, dim3(n_row_blocks + n_cross_blocks + (split ? 0 : n_base_blocks), n_chrom), dim3(256), lds, s,
+                       steps, n_base_blocks, n_row_blocks, n_cross_blocks);
 }
 
 // ---- window: G table ----------------------------------------------------------------------------
