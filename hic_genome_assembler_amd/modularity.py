@@ -60,7 +60,12 @@ class _Status:
 
 
 def _one_level(st: _Status, rng):
+    """One level of python-louvain's __one_level.  The sweep over the nodes is sequential (every move changes the
+    state the next node sees); what one node does - the weights to every community, the communities present among
+    the OTHER nodes, the best gain over them in shuffled order (first maximum wins, as the reference's strict `>`
+    loop) - is array work: O(n) per node instead of a sort plus a Python loop over the communities."""
     A, n = st.A, len(st.A)
+    sizes = np.bincount(st.node2com, minlength=n)                          # members per community
     modified, new_mod = True, st.modularity()
     while modified:
         cur_mod, modified = new_mod, False
@@ -70,23 +75,28 @@ def _one_level(st: _Status, rng):
             # weight from `node` to every community (the graph is complete: every community is a neighbour)
             row = A[node].copy()
             row[node] = 0.0
-            coms = st.node2com
-            present = np.unique(np.delete(coms, node)) if n > 1 else np.zeros(0, dtype=coms.dtype)
-            w_to = np.bincount(coms, weights=row, minlength=n)
-            w_own = w_to[com_node] if com_node in present else 0.0
+            sizes[com_node] -= 1
+            present = np.flatnonzero(sizes)                                # communities of the other nodes, ascending
+            w_to = np.bincount(st.node2com, weights=row, minlength=n)
+            w_own = w_to[com_node] if sizes[com_node] > 0 else 0.0
             remove_cost = -w_own + (st.degrees[com_node] - st.gdegrees[node]) * degc_totw
             # __remove
             st.degrees[com_node] -= st.gdegrees[node]
             st.internals[com_node] -= w_own + st.loops[node]
             st.node2com[node] = -1
             best_com, best_increase = com_node, 0.0
-            for com in rng.permutation(present):
-                incr = remove_cost + w_to[com] - st.degrees[com] * degc_totw
-                if incr > best_increase:
-                    best_increase, best_com = incr, com
+            if len(present):
+                order = rng.permutation(present)
+                incr = remove_cost + w_to[order] - st.degrees[order] * degc_totw
+                k = int(np.argmax(incr))                                   # first maximum in the shuffled order
+                if incr[k] > best_increase:
+                    best_increase, best_com = float(incr[k]), order[k]
+            else:
+                rng.permutation(present)                                   # (keeps the generator's stream as before)
             # __insert
-            w_best = w_to[best_com] if best_com in present else 0.0
+            w_best = w_to[best_com] if sizes[best_com] > 0 else 0.0
             st.node2com[node] = best_com
+            sizes[best_com] += 1
             st.degrees[best_com] += st.gdegrees[node]
             st.internals[best_com] += w_best + st.loops[node]
             if best_com != com_node:
