@@ -690,13 +690,16 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
     // of the live columns), with the scans counted by the kernels themselves (a scan the neighbour cache answers moves
     // nothing); the merge term is 3 * 8 * sum_{k=0}^{n-2} (n - k).
     const bool prof_on = getenv("HICMI_NNCHAIN_PROFILE") != nullptr;
-    const char* cap = getenv("HICMI_NNCHAIN_DCAP");               // merges between two column flushes (tests shrink it)
+    // merges between two column flushes = merges per epoch launch.  Every row a merge reads is patched at the columns
+    // whose writes are still deferred, so a merge's cost grows with the list: 1024 -> 256 merges per epoch took the chain
+    // from 124.8 to 118.0 ms at 16k and from 282.5 to 272.4 ms at 32k (128: no further gain - ~40 us of launches per epoch)
+    const char* cap = getenv("HICMI_NNCHAIN_DCAP");
     struct { int state[16]; unsigned long long prof[8]; unsigned char mail[640]; unsigned long long detail[32]; } nn;   // the head of the workspace
     for (int attempt = 0; attempt < 2; attempt++) {
         {
             Timed t(c, F_NNCHAIN, 0.0);
             int epochs = launch_nnchain(c->dW, c->dW2, ldw, (int)n, c->d_chain, c->d_zraw, c->d_size, prof_on,
-                                        cap ? atoi(cap) : 1024, getenv("HICMI_NNCHAIN_NO_COMPACT") == nullptr, attempt > 0, c->stream);
+                                        cap ? atoi(cap) : 256, getenv("HICMI_NNCHAIN_NO_COMPACT") == nullptr, attempt > 0, c->stream);
             // the family is reported per epoch launch (the flush / compaction launches in between are ~1 % of it)
             if (epochs > 1) c->launches[F_NNCHAIN] += epochs - 1;
         }
