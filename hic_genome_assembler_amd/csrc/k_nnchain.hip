@@ -218,6 +218,8 @@ struct NNWorkspace {
     double* nnval;              // n: neighbour cache - distance to the nearest live cluster of each slot
     uint32_t* nnc;              // n: neighbour cache - its slot (low 16 bits, 0xffff = unknown) | tie flag << 16
     double* rec;                // NN_MAXWG x NN_DMAX x 4: the merges of the last epoch as every replica of k_nn_epoch_mw saw them
+    int* size_rep;              // NN_MAXWG x n: cluster sizes, one private copy per replica of k_nn_epoch_mwc<.., .., true> (rows
+                                // beyond 32,768 columns: the sizes do not fit the LDS beside the neighbour cache)
 };
 static constexpr int NN_STOP_GUARD = 1, NN_STOP_LATE = 2, NN_STOP_DIVERGED = 3;
 static constexpr uint32_t NN_NOIDX = 0xffffu;
@@ -228,7 +230,8 @@ size_t nnchain_workspace_bytes(int n)
 {
     size_t nwords = (size_t)(n + 31) / 32;
     return 1024 + align16(nwords * 4) + align16((size_t)n * 2) + 4 * align16((size_t)n * 4) + 2 * align16(NN_DMAX * 4) +
-           align16((size_t)n * 8) + align16((size_t)n * 4) + (size_t)NN_MAXWG * NN_DMAX * 4 * 8;
+           align16((size_t)n * 8) + align16((size_t)n * 4) + (size_t)NN_MAXWG * NN_DMAX * 4 * 8 +
+           (size_t)NN_MAXWG * align16((size_t)n * 4);
 }
 
 static NNWorkspace carve(void* ws, int n)
@@ -250,7 +253,8 @@ static NNWorkspace carve(void* ws, int n)
     w.oldidx = reinterpret_cast<int*>(p); p += align16((size_t)n * 4);
     w.nnval = reinterpret_cast<double*>(p); p += align16((size_t)n * 8);
     w.nnc = reinterpret_cast<uint32_t*>(p); p += align16((size_t)n * 4);
-    w.rec = reinterpret_cast<double*>(p);
+    w.rec = reinterpret_cast<double*>(p); p += (size_t)NN_MAXWG * NN_DMAX * 4 * 8;
+    w.size_rep = reinterpret_cast<int*>(p);
     return w;
 }
 
@@ -1208,8 +1212,13 @@ __device__ __forceinline__ int mwc_tie(u32x4 p) { return (int)((p.w >> 17) & 1u)
 __device__ __forceinline__ int mwc_event(u32x4 p) { return (int)((p.w >> 18) & 1u); }
 
 static constexpr int NN_MWC_MAX = 32768;                 // sizes + cache of every column in the LDS of every replica
+static constexpr int NN_MWC_GMAX = 65535;                // GSIZE: the cache alone in LDS (2 bytes per column; 0xffff = unknown),
+                                                         // the sizes in a private global array per replica - as far as the
+                                                         // 160 KB go (launch_nnchain checks: 64,000 columns fit)
 
-template <int NWG, bool PROF>
+// GSIZE: cluster sizes in global memory (w.size_rep, one copy per workgroup, read and written by lane 0 with L1-bypassing
+// accesses: two loads per merge on the critical path, ~0.7 us where a merge costs ~13) instead of in LDS.
+template <int NWG, bool PROF, bool GSIZE = false>
 __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict__ W, int64_t ld, int n,
                                                              int* __restrict__ chain_all, double* __restrict__ zraw,
                                                              NNWorkspace w, int dcap, int total_steps)
@@ -1220,7 +1229,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
     uint32_t* smask = alive + nw4;
     uint32_t* tieb = smask + nw4;
     uint16_t* lsize = reinterpret_cast<uint16_t*>(tieb + nw4);
-    uint16_t* nnidx = lsize + n2;
+    uint16_t* nnidx = GSIZE ? lsize : lsize + n2;
     __shared__ int dslot[NN_DMAX], dtime[NN_DMAX];
     __shared__ double s_v[32];
     __shared__ int s_i[32], s_t[32];
@@ -1230,6 +1239,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
         s_a_i, s_a_t;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
+    int* __restrict__ gsize = w.size_rep + (int64_t)wg * (((int64_t)n + 3) & ~(int64_t)3);   // (GSIZE only)
     int* __restrict__ chain = chain_all + (int64_t)wg * (n + 2);           // every workgroup keeps its own copy
     u32x4* mail = reinterpret_cast<u32x4*>(w.mail);
     int step = w.state[0];
@@ -1244,11 +1254,13 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
     for (int i = tid; i < nwords; i += NN_THREADS) { alive[i] = w.alive[i]; smask[i] = w.alive[i]; tieb[i] = 0u; }
     __syncthreads();
     for (int i = tid; i < n; i += NN_THREADS) {
-        lsize[i] = w.size[i];
+        if (GSIZE) __hip_atomic_store(gsize + i, (int)w.size[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else lsize[i] = w.size[i];
         const uint32_t c = w.nnc[i];
         nnidx[i] = (uint16_t)(c & 0xffffu);
         if (c >> 16) atomicOr(&tieb[i >> 5], 1u << (i & 31));
     }
+    if (GSIZE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int len = w.state[1], top = w.state[2], second = w.state[3], first_ptr = w.state[4];
     if (tid == 0) { s_stop = 0; s_ev = 0; }
     const int* __restrict__ chain0 = chain_all;             // chain prefix of the earlier epochs: workgroup 0's copy
@@ -1413,9 +1425,17 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
             int xx = top, yy = second;
             len -= 2;
             if (xx > yy) { int t = xx; xx = yy; yy = t; }
-            int nx = lsize[xx], ny = lsize[yy];
-            lsize[xx] = 0;
-            lsize[yy] = (uint16_t)(nx + ny);
+            int nx, ny;
+            if (GSIZE) {
+                nx = __hip_atomic_load(gsize + xx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ny = __hip_atomic_load(gsize + yy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gsize + xx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gsize + yy, nx + ny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                nx = lsize[xx]; ny = lsize[yy];
+                lsize[xx] = 0;
+                lsize[yy] = (uint16_t)(nx + ny);
+            }
             atomicAnd(&alive[xx >> 5], ~(1u << (xx & 31)));
             atomicAnd(&smask[xx >> 5], ~(1u << (xx & 31)));
             s_mx = xx; s_my = yy; s_nx = nx; s_ny = ny; s_tx = -1; s_ty = -1; s_ey = -1; s_ta = -1;
@@ -1682,11 +1702,13 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
         // no barrier here: lane 0 goes straight into the next walk, everybody else to the barrier behind it
         if (prof) { const unsigned long long t1 = wall_clock64(); s_tp[2] += t1 - t0; }
     }
+    if (GSIZE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (wg != 0) return;
     for (int i = tid; i < nwords; i += NN_THREADS) w.alive[i] = alive[i];
     for (int i = tid; i < n; i += NN_THREADS) {
-        w.size[i] = lsize[i]; w.gtime[i] = -1;
+        w.size[i] = GSIZE ? (uint16_t)__hip_atomic_load(gsize + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : lsize[i];
+        w.gtime[i] = -1;
         w.nnc[i] = (uint32_t)nnidx[i] | (((tieb[i >> 5] >> (i & 31)) & 1u) << 16);
     }
     __syncthreads();
@@ -1828,8 +1850,13 @@ static void launch_mwc_n(bool profile, size_t lds, hipStream_t s, double* cur, i
 }
 
 static void launch_mwc(int wgs, bool profile, size_t lds, hipStream_t s, double* cur, int64_t ldw, int n_cur, int* chain,
-                       double* zraw, NNWorkspace w, int dcap, int total_steps)
+                       double* zraw, NNWorkspace w, int dcap, int total_steps, bool gsize = false)
 {
+    if (gsize) {                                           // (eight slices only: what rows beyond 32,768 columns use)
+        if (profile) hipLaunchKernelGGL((k_nn_epoch_mwc<8, true, true>), dim3(8), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+        else hipLaunchKernelGGL((k_nn_epoch_mwc<8, false, true>), dim3(8), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+        return;
+    }
     if (wgs == 1) launch_mwc_n<1>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
     else if (wgs == 2) launch_mwc_n<2>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
     else if (wgs == 4) launch_mwc_n<4>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
@@ -1843,6 +1870,31 @@ static void mwc_set_lds(int bytes)
                          reinterpret_cast<const void*>(k_nn_epoch_mwc<4, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<4, true>),
                          reinterpret_cast<const void*>(k_nn_epoch_mwc<8, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<8, true>)};
     for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+// Largest row the GSIZE variant can take: bitmaps (12 bytes per 32 columns) + cache (2 bytes per column) + the kernel's
+// static LDS within the 160 KB of a CU.  Also raises the kernels' dynamic-LDS limit to what is left.
+static int mwc_gsize_max_columns()
+{
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    size_t stat = 0;
+    const void* fns[] = {reinterpret_cast<const void*>(k_nn_epoch_mwc<8, false, true>), reinterpret_cast<const void*>(k_nn_epoch_mwc<8, true, true>)};
+    for (const void* f : fns) {
+        hipFuncAttributes a;
+        if (hipFuncGetAttributes(&a, f) != hipSuccess) { cached = 0; return 0; }
+        if (a.sharedSizeBytes > stat) stat = a.sharedSizeBytes;
+    }
+    const size_t room = 160 * 1024 > stat + 256 ? 160 * 1024 - stat - 256 : 0;
+    for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)room);
+    int n = NN_MWC_GMAX;
+    while (n > 0) {
+        const size_t nw4 = ((((size_t)n + 31) / 32) + 3) & ~(size_t)3;
+        if (align16(nw4 * 12 + (((size_t)n + 7) & ~(size_t)7) * 2) <= room) break;
+        n -= 64;
+    }
+    cached = n > 0 ? n : 0;
+    return cached;
 }
 
 // W and W2: two n x ldw buffers (W holds the distances on entry; both are scratch afterwards).
@@ -1866,6 +1918,8 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     const bool plain = getenv("HICMI_NNCHAIN_PLAIN") != nullptr;
     const bool fused1 = getenv("HICMI_NNCHAIN_FUSED1") != nullptr;       // narrow epochs on k_nn_epoch_mwc<1> instead of k_nn_epoch_nc
     const bool mw_old = getenv("HICMI_NNCHAIN_MW_OLD") != nullptr;       // k_nn_epoch_mw also where k_nn_epoch_mwc would fit (A/B, tests)
+    const bool force_gsize = getenv("HICMI_NNCHAIN_GSIZE") != nullptr;   // the GSIZE variant of k_nn_epoch_mwc at every width (tests)
+    const int gsize_max = (n > NN_MWC_MAX || force_gsize) ? mwc_gsize_max_columns() : 0;
     if (dcap < 1) dcap = 1;
     if (dcap > NN_DMAX) dcap = NN_DMAX;
     hipLaunchKernelGGL(k_nn_init, dim3(64), dim3(256), 0, s, w, n);
@@ -1900,13 +1954,16 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
         const int nwords = (n_cur + 31) / 32, nw4 = (nwords + 3) & ~3;
         const size_t lds = align16((size_t)nw4 * 8 + (size_t)n_cur * 2);
         const bool sliced = wgs > 1 && n_cur >= mw_from;
-        if (sliced && !plain && !mw_old && n_cur <= NN_MWC_MAX) {
+        // rows beyond 32,768 columns (or HICMI_NNCHAIN_GSIZE=1: all, for the tests): cluster sizes in global memory, the
+        // cache alone in LDS - 64,000 columns fit; eight slices only
+        const bool gsize = wgs == 8 && (n_cur > NN_MWC_MAX || force_gsize) && n_cur <= gsize_max;
+        if (sliced && !plain && !mw_old && (n_cur <= NN_MWC_MAX || gsize)) {
             // column slices + neighbour cache + the next scan fused into the update (k_nn_epoch_mwc)
             if (!cache_valid) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
             cache_valid = true;
-            const size_t lds_c = align16((size_t)nw4 * 12 + (size_t)((n_cur + 7) & ~7) * 4);
+            const size_t lds_c = align16((size_t)nw4 * 12 + (size_t)((n_cur + 7) & ~7) * (gsize ? 2 : 4));
             hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 640, s);      // mailboxes
-            launch_mwc(wgs, profile, lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+            launch_mwc(wgs, profile, lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, gsize);
             hipLaunchKernelGGL(k_nn_check_replicas, dim3((NN_DMAX + 255) / 256), dim3(256), 0, s, w, wgs);
         }
         else if (sliced) {

@@ -141,6 +141,55 @@ def test_upgma_column_sliced_chain_bit_exact(hic, orc, monkeypatch, n, seed, dca
     assert np.array_equal(leaves, leaves_o)
 
 
+@pytest.mark.parametrize("n,seed,dcap", [(130, 1, 7), (1025, 6, 256), (4099, 8, 300)])
+def test_upgma_cluster_sizes_in_global_memory_bit_exact(hic, orc, monkeypatch, n, seed, dcap):
+    """k_nn_epoch_mwc<8, ., true>: what rows beyond 32,768 columns run on - the neighbour cache alone in LDS, the cluster
+    sizes in a private global array per workgroup.  HICMI_NNCHAIN_GSIZE=1 selects it at every width, here against the
+    oracle (random and tie-heavy distances)."""
+    monkeypatch.setenv("HICMI_NNCHAIN_WGS", "8")
+    monkeypatch.setenv("HICMI_NNCHAIN_GSIZE", "1")
+    monkeypatch.setenv("HICMI_NNCHAIN_DCAP", str(dcap))
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, n)) + 0.01
+    c = c + c.T
+    for _ in range(2):
+        leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, c)
+        assert np.array_equal(zraw, zraw_o)
+        assert np.array_equal(leaves, leaves_o)
+    ties = rng.integers(1, 4, size=(n, n)).astype(np.float64)
+    ties = np.triu(ties, 1) + np.triu(ties, 1).T + np.eye(n)
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, ties)
+    assert np.array_equal(zraw, zraw_o)
+    assert np.array_equal(leaves, leaves_o)
+
+
+def test_upgma_wide_rows_cached_and_uncached_agree_at_40k(hic, monkeypatch):
+    """40,000 bins: the first epochs have more than 32,768 live columns and run on the GSIZE variant of the cached
+    kernel; HICMI_NNCHAIN_MW_OLD=1 runs them on k_nn_epoch_mw (no cache: the round-1 kernel the 64k tests of round 1
+    pinned).  Same merges, and fewer row scans (on uniform random distances the cache saves far less than on Hi-C maps:
+    2.3 scans per merge against 2.9; the 64k bench map runs at 1.28)."""
+    import torch
+    n = 40000
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(9)
+    c = torch.rand((n, n), generator=g, device="cuda:0", dtype=torch.float64)
+    c = c + c.T + 0.01
+    torch.cuda.synchronize()
+    got = []
+    with hic.Context(0) as ctx:
+        ctx.set_contacts_device(c.data_ptr(), n, keepalive=c)
+        for old in (False, True):
+            if old:
+                monkeypatch.setenv("HICMI_NNCHAIN_MW_OLD", "1")
+            ctx.timing_reset()
+            leaves, _z = ctx.upgma()
+            got.append((np.array(leaves), ctx.raw_merges().copy(), ctx.nnchain_stats()))
+    assert np.array_equal(got[0][1], got[1][1])
+    assert np.array_equal(got[0][0], got[1][0])
+    assert sorted(got[0][0].tolist()) == list(range(n))
+    assert got[0][2]["scans"] < 0.85 * got[1][2]["scans"]
+
+
 def test_upgma_column_sliced_chain_default_width_at_scale(hic, orc):
     """21,000 bins: above the width switch, so the first epochs run on 8 workgroups and the later ones - once
     compaction has shrunk the matrix below it - on one, sharing the saved chain state."""
