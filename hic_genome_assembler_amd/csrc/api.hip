@@ -675,7 +675,7 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         free_dev(c->d_size); free_dev(c->d_chain); free_dev(c->d_zraw); free_dev(c->d_status);
         c->d_size = c->d_chain = c->d_status = nullptr; c->d_zraw = nullptr;
         HIPCHK(hipMalloc((void**)&c->d_size, nnchain_workspace_bytes((int)n)));
-        HIPCHK(hipMalloc((void**)&c->d_chain, sizeof(int) * 8 * (size_t)(n + 2)));      // one copy per workgroup of k_nn_epoch_mw
+        HIPCHK(hipMalloc((void**)&c->d_chain, sizeof(int) * 16 * (size_t)(n + 2)));     // one copy per workgroup of k_nn_epoch_mw / _mwc
         HIPCHK(hipMalloc((void**)&c->d_zraw, sizeof(double) * 4 * (size_t)n));
         HIPCHK(hipMalloc((void**)&c->d_status, sizeof(int)));
     }
@@ -694,7 +694,7 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
     // whose writes are still deferred, so a merge's cost grows with the list: 1024 -> 256 merges per epoch took the chain
     // from 124.8 to 118.0 ms at 16k and from 282.5 to 272.4 ms at 32k (128: no further gain - ~40 us of launches per epoch)
     const char* cap = getenv("HICMI_NNCHAIN_DCAP");
-    struct { int state[16]; unsigned long long prof[8]; unsigned char mail[640]; unsigned long long detail[32]; } nn;   // the head of the workspace
+    struct { int state[16]; unsigned long long prof[8]; unsigned char mail[1152]; unsigned long long detail[32]; } nn;   // the head of the workspace
     for (int attempt = 0; attempt < 2; attempt++) {
         {
             Timed t(c, F_NNCHAIN, 0.0);

@@ -27,7 +27,8 @@ namespace hicmi {
 
 static constexpr int NN_THREADS = 1024;
 static constexpr int NN_DMAX = 1024;                     // at most one dirty entry per lane
-static constexpr int NN_MAXWG = 8;                       // workgroups of the column-sliced chain (k_nn_epoch_mw)
+static constexpr int NN_MAXWG = 16;                      // workgroups of the column-sliced chain (k_nn_epoch_mw / _mwc)
+static constexpr int NN_HEAD = 1536;                     // state 64 B, counters 64 B, hand-off slot 128 B, mailboxes 1024 B, profile detail 256 B
 
 struct ArgMin { double v; int i; };
 
@@ -229,7 +230,7 @@ static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 size_t nnchain_workspace_bytes(int n)
 {
     size_t nwords = (size_t)(n + 31) / 32;
-    return 1024 + align16(nwords * 4) + align16((size_t)n * 2) + 4 * align16((size_t)n * 4) + 2 * align16(NN_DMAX * 4) +
+    return NN_HEAD + align16(nwords * 4) + align16((size_t)n * 2) + 4 * align16((size_t)n * 4) + 2 * align16(NN_DMAX * 4) +
            align16((size_t)n * 8) + align16((size_t)n * 4) + (size_t)NN_MAXWG * NN_DMAX * 4 * 8 +
            (size_t)NN_MAXWG * align16((size_t)n * 4);
 }
@@ -242,7 +243,7 @@ static NNWorkspace carve(void* ws, int n)
     w.state = reinterpret_cast<int*>(p);
     w.prof = reinterpret_cast<unsigned long long*>(p + 64);
     w.mail = p + 256;                                        // 2 parities x NN_MAXWG workgroups x 2 slots x 16 bytes
-    p += 1024;
+    p += NN_HEAD;
     w.alive = reinterpret_cast<uint32_t*>(p); p += align16(nwords * 4);
     w.size = reinterpret_cast<uint16_t*>(p); p += align16((size_t)n * 2);
     w.gtime = reinterpret_cast<int*>(p); p += align16((size_t)n * 4);
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void k_nn_init(NNWorkspace w, int n)
     for (int i = gid; i < n; i += stride) { w.size[i] = 1; w.gtime[i] = -1; w.orig[i] = i; }
     if (gid < 16) w.state[gid] = 0;
     if (gid < 8) w.prof[gid] = 0ull;
-    if (gid < 32) reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(w.state) + 768)[gid] = 0ull;   // profile detail
+    if (gid < 32) reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(w.state) + 1280)[gid] = 0ull;   // profile detail
 }
 
 // PROFILE adds wall-clock stamps (100 MHz) around the phases, accumulated in w.prof[0..4] =
@@ -1723,7 +1724,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
             for (int q = 0; q < 4; q++) w.prof[q] += s_tp[q];
             // detail of the fused pass (profile builds only): issue gathers / LDS pass / loads arrive / compute + stores /
             // gathered values + reductions / stores acknowledged / barrier - and the "update" phase is their sum
-            unsigned long long* p2 = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(w.state) + 768);
+            unsigned long long* p2 = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(w.state) + 1280);
             unsigned long long upd = 0;
             for (int q = 0; q < 7; q++) { p2[q] += s_tp[8 + q]; upd += s_tp[8 + q]; }
             w.prof[4] += upd;
@@ -1852,12 +1853,18 @@ static void launch_mwc_n(bool profile, size_t lds, hipStream_t s, double* cur, i
 static void launch_mwc(int wgs, bool profile, size_t lds, hipStream_t s, double* cur, int64_t ldw, int n_cur, int* chain,
                        double* zraw, NNWorkspace w, int dcap, int total_steps, bool gsize = false)
 {
-    if (gsize) {                                           // (eight slices only: what rows beyond 32,768 columns use)
-        if (profile) hipLaunchKernelGGL((k_nn_epoch_mwc<8, true, true>), dim3(8), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
-        else hipLaunchKernelGGL((k_nn_epoch_mwc<8, false, true>), dim3(8), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+    if (gsize) {                                           // (8 or 16 slices: what rows beyond 32,768 columns use)
+        if (wgs == 16) {
+            if (profile) hipLaunchKernelGGL((k_nn_epoch_mwc<16, true, true>), dim3(16), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+            else hipLaunchKernelGGL((k_nn_epoch_mwc<16, false, true>), dim3(16), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+        } else {
+            if (profile) hipLaunchKernelGGL((k_nn_epoch_mwc<8, true, true>), dim3(8), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+            else hipLaunchKernelGGL((k_nn_epoch_mwc<8, false, true>), dim3(8), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+        }
         return;
     }
-    if (wgs == 1) launch_mwc_n<1>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+    if (wgs == 16) launch_mwc_n<16>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+    else if (wgs == 1) launch_mwc_n<1>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
     else if (wgs == 2) launch_mwc_n<2>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
     else if (wgs == 4) launch_mwc_n<4>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
     else launch_mwc_n<8>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
@@ -1868,7 +1875,8 @@ static void mwc_set_lds(int bytes)
     const void* fns[] = {reinterpret_cast<const void*>(k_nn_epoch_mwc<1, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<1, true>),
                          reinterpret_cast<const void*>(k_nn_epoch_mwc<2, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<2, true>),
                          reinterpret_cast<const void*>(k_nn_epoch_mwc<4, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<4, true>),
-                         reinterpret_cast<const void*>(k_nn_epoch_mwc<8, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<8, true>)};
+                         reinterpret_cast<const void*>(k_nn_epoch_mwc<8, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<8, true>),
+                         reinterpret_cast<const void*>(k_nn_epoch_mwc<16, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<16, true>)};
     for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
@@ -1879,7 +1887,8 @@ static int mwc_gsize_max_columns()
     static int cached = -1;
     if (cached >= 0) return cached;
     size_t stat = 0;
-    const void* fns[] = {reinterpret_cast<const void*>(k_nn_epoch_mwc<8, false, true>), reinterpret_cast<const void*>(k_nn_epoch_mwc<8, true, true>)};
+    const void* fns[] = {reinterpret_cast<const void*>(k_nn_epoch_mwc<8, false, true>), reinterpret_cast<const void*>(k_nn_epoch_mwc<8, true, true>),
+                         reinterpret_cast<const void*>(k_nn_epoch_mwc<16, false, true>), reinterpret_cast<const void*>(k_nn_epoch_mwc<16, true, true>)};
     for (const void* f : fns) {
         hipFuncAttributes a;
         if (hipFuncGetAttributes(&a, f) != hipSuccess) { cached = 0; return 0; }
@@ -1910,7 +1919,12 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     // HICMI_NNCHAIN_PLAIN=1 selects the cache-less k_nn_epoch instead (A/B, and the reference point of the tests).
     const char* wgs_text = force_single ? "1" : getenv("HICMI_NNCHAIN_WGS");
     const int wgs_env = wgs_text ? atoi(wgs_text) : 0;
-    const int wgs = wgs_text ? (wgs_env >= 8 ? 8 : (wgs_env >= 4 ? 4 : (wgs_env >= 2 ? 2 : 1))) : 8;
+    const int wgs = wgs_text ? (wgs_env >= 16 ? 16 : (wgs_env >= 8 ? 8 : (wgs_env >= 4 ? 4 : (wgs_env >= 2 ? 2 : 1)))) : 8;
+    // 16 slices instead of 8 while the rows are long: a merge costs ~7.4 / 8.5 / 11.4 us at 2,000 / 4,000 / 8,000 columns per
+    // slice, and the sixteen-way exchange only a little more than the eight-way one.  Measured (nn-chain per map, threshold
+    // off / 24,000 / 16,000 / 12,000 live columns): 32k 272 / 264 / 256 / 259 ms, 64k 730 / 682 / 678 / - ms, 16k 118.3 / - / - / 116.8
+    const char* w16_text = getenv("HICMI_NNCHAIN_W16_FROM");
+    const int w16_from = wgs_text ? 0x7fffffff : (w16_text ? atoi(w16_text) : 14000);
     const char* from_text = getenv("HICMI_NNCHAIN_MW_FROM");
     // live columns from which an epoch runs sliced: with the cache and the fused scan a merge costs ~1.3 exchanges instead
     // of ~2.9, so eight slices pay from ~6,000 columns on (16k map: nn-chain 200 -> 153 ms; 4,000 and 8,000 measure the same)
@@ -1954,24 +1968,25 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
         const int nwords = (n_cur + 31) / 32, nw4 = (nwords + 3) & ~3;
         const size_t lds = align16((size_t)nw4 * 8 + (size_t)n_cur * 2);
         const bool sliced = wgs > 1 && n_cur >= mw_from;
+        const int wgs_e = n_cur >= w16_from ? 16 : wgs;            // this epoch's width (k_nn_epoch_mwc only)
         // rows beyond 32,768 columns (or HICMI_NNCHAIN_GSIZE=1: all, for the tests): cluster sizes in global memory, the
-        // cache alone in LDS - 64,000 columns fit; eight slices only
-        const bool gsize = wgs == 8 && (n_cur > NN_MWC_MAX || force_gsize) && n_cur <= gsize_max;
+        // cache alone in LDS - 64,000 columns fit; 8 or 16 slices
+        const bool gsize = wgs_e >= 8 && (n_cur > NN_MWC_MAX || force_gsize) && n_cur <= gsize_max;
         if (sliced && !plain && !mw_old && (n_cur <= NN_MWC_MAX || gsize)) {
             // column slices + neighbour cache + the next scan fused into the update (k_nn_epoch_mwc)
             if (!cache_valid) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
             cache_valid = true;
             const size_t lds_c = align16((size_t)nw4 * 12 + (size_t)((n_cur + 7) & ~7) * (gsize ? 2 : 4));
-            hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 640, s);      // mailboxes
-            launch_mwc(wgs, profile, lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, gsize);
-            hipLaunchKernelGGL(k_nn_check_replicas, dim3((NN_DMAX + 255) / 256), dim3(256), 0, s, w, wgs);
+            hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 1152, s);      // mailboxes
+            launch_mwc(wgs_e, profile, lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, gsize);
+            hipLaunchKernelGGL(k_nn_check_replicas, dim3((NN_DMAX + 255) / 256), dim3(256), 0, s, w, wgs_e);
         }
         else if (sliced) {
-            hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 640, s);      // hand-off slot + mailboxes
+            hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 1152, s);      // hand-off slot + mailboxes
             if (wgs == 2) hipLaunchKernelGGL(k_nn_epoch_mw<2>, dim3(2), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
             else if (wgs == 4) hipLaunchKernelGGL(k_nn_epoch_mw<4>, dim3(4), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
             else hipLaunchKernelGGL(k_nn_epoch_mw<8>, dim3(8), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
-            hipLaunchKernelGGL(k_nn_check_replicas, dim3((NN_DMAX + 255) / 256), dim3(256), 0, s, w, wgs);
+            hipLaunchKernelGGL(k_nn_check_replicas, dim3((NN_DMAX + 255) / 256), dim3(256), 0, s, w, wgs > 8 ? 8 : wgs);
             cache_valid = false;
         }
         else if (!plain && fused1 && n_cur <= NN_MWC_MAX) {
@@ -1979,7 +1994,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
             if (!cache_valid) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
             cache_valid = true;
             const size_t lds_c = align16((size_t)nw4 * 12 + (size_t)((n_cur + 7) & ~7) * 4);
-            hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 640, s);
+            hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 1152, s);
             launch_mwc(1, profile, lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
         }
         else if (!plain && n_cur <= NN_NC_MAX) {

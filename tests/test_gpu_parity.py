@@ -115,10 +115,11 @@ def test_upgma_beyond_one_streaming_pass_bit_exact(hic, orc):
 
 
 @pytest.mark.parametrize("kernel", ["mwc", "mw"])
-@pytest.mark.parametrize("wgs", [2, 4, 8])
+@pytest.mark.parametrize("wgs", [2, 4, 8, 16])
 @pytest.mark.parametrize("n,seed,dcap", [(130, 1, 7), (600, 2, 64), (1025, 6, 1024), (2500, 7, 1024), (4099, 8, 300)])
 def test_upgma_column_sliced_chain_bit_exact(hic, orc, monkeypatch, n, seed, dcap, wgs, kernel):
-    """The chain as 2, 4 or 8 workgroups that each stream a slice of the columns and exchange their (min, index):
+    """The chain as 2, 4, 8 or 16 workgroups (16: k_nn_epoch_mwc only, the width of the epochs with 24,000 live columns or
+    more; the older kernel then runs on 8) that each stream a slice of the columns and exchange their (min, index):
     k_nn_epoch_mwc (neighbour cache replicated in every workgroup, the next scan fused into the update: the default
     for the wide epochs up to 32,768 live columns) and k_nn_epoch_mw (one exchange per scan, no cache: wider epochs).
     Forced here for every epoch that is wide enough.  Run three times: the exchange is timing-dependent, the linkage
@@ -146,7 +147,7 @@ def test_upgma_cluster_sizes_in_global_memory_bit_exact(hic, orc, monkeypatch, n
     """k_nn_epoch_mwc<8, ., true>: what rows beyond 32,768 columns run on - the neighbour cache alone in LDS, the cluster
     sizes in a private global array per workgroup.  HICMI_NNCHAIN_GSIZE=1 selects it at every width, here against the
     oracle (random and tie-heavy distances)."""
-    monkeypatch.setenv("HICMI_NNCHAIN_WGS", "8")
+    monkeypatch.setenv("HICMI_NNCHAIN_WGS", "16" if n == 4099 else "8")
     monkeypatch.setenv("HICMI_NNCHAIN_GSIZE", "1")
     monkeypatch.setenv("HICMI_NNCHAIN_DCAP", str(dcap))
     rng = np.random.default_rng(seed)
