@@ -17,8 +17,10 @@ Rank 0 prints ONE JSON line (contract in the task prompt) with these extra objec
   cpu_baseline   - the CPU oracle (a port of the reference's NumPy/SciPy path, oracle/) timed on this box's host
                    cores on BASELINE configs[0] (2,000 bins), with and without the reference's unused
                    frozen-distribution construction (scaffoldToChromosomes.py:364).
-N > 1: ONE map over all ranks (strong scaling): Part 1's row-independent stages and Part 2's chromosomes are
-sharded (hic_genome_assembler_amd/dist.py); --weak runs one independent map per rank instead.
+N > 1: ONE map over all ranks (strong scaling): Part 2's chromosomes are dealt to the ranks, Part 1 runs on every rank
+(its chain does not shard and, since its scans take their decisions on the device, sharding the per-row stages costs
+more in per-scan all-gathers than it saves: DESIGN.md section 7); --shard-part1 row-shards those stages all the same
+(hic_genome_assembler_amd/dist.py); --weak runs one independent map per rank instead.
 """
 import argparse
 import contextlib
@@ -195,6 +197,7 @@ class Job:
         from hic_genome_assembler_amd import _lib, synth
         from hic_genome_assembler_amd.hostio import Bin
         self.args, self.n, self.shard = args, n, shard
+        self.shard_p1 = shard                              # Part 1's row shard (bench default: None - Part 1 on every rank)
         self.lay = synth.make_layout(n, seed=seed)
         self.contacts = synth.dense_contacts_torch(self.lay, dev, seed=seed, sinkhorn_iters=12)
         if f32:                                            # configs[4]: contacts stored as fp32 (exactly representable values)
@@ -222,7 +225,7 @@ class Job:
             # starts from the in-memory groups); finish_files() below is inside the timed step: all six files are on disk
             # when it returns
             cuts = p1.runResident(dm, list(self.bins), self.sizes, f("dendrogramOrder.txt"), f("binGroups.txt"),
-                                  f("assessment.txt"), f("chromosomeGroups.txt"), 5, 0.0, .05, shard=self.shard,
+                                  f("assessment.txt"), f("chromosomeGroups.txt"), 5, 0.0, .05, shard=self.shard_p1,
                                   overlap_files=True)
             self.last["part1_s"] = time.perf_counter() - ta
             if not a.part1_only:
@@ -307,6 +310,8 @@ def main():
     ap.add_argument("--weak", action="store_true",
                     help="N > 1: one independent map per rank (weak scaling) instead of ONE map over all ranks")
     ap.add_argument("--one-map", action="store_true", help="(default for N > 1; kept for earlier command lines)")
+    ap.add_argument("--shard-part1", action="store_true",
+                    help="N > 1, one map: also row-shard Part 1's row sums / rank rows / scan counts (one all-gather per scan)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearse the multi-rank flow with several ranks on one GPU")
     ap.add_argument("--kernel-times", choices=["part1", "all"], default="part1",
@@ -333,6 +338,8 @@ def main():
 
     n = args.bins
     job = Job(args, n, dev, local, map_seed, shard, f32=args.f32)
+    if not args.shard_part1:
+        job.shard_p1 = None
     timing_mode = 0 if os.environ.get("HICMI_BENCH_NO_TIMING") else (1 if args.kernel_times == "all" else 2)
     # HIP events around the families that decide the roofline line (nn-chain, row sort, ...).  --kernel-times all
     # also brackets the hundreds of small launches of the scans and of Part 2, which costs about 10 ms per map.
@@ -361,9 +368,11 @@ def main():
                        "part1_s_per_step": round(job.parts[0] / max(job.parts[2], 1), 4),
                        "part2_s_per_step": round(job.parts[1] / max(job.parts[2], 1), 4),
                        "part2_workers": p2.WORKERS, "ranks": world,
-                       "parallelism": ("ONE map over %d ranks: Part 1's row-independent stages (row sums, row sort / rank "
-                                       "matrix, cut and filter counts) row-blocked with an all-gather of the per-row counts, "
-                                       "UPGMA replicated, Part 2's chromosomes dealt to the ranks" % world) if one_map
+                       "parallelism": (("ONE map over %d ranks: Part 1's row-independent stages (row sums, rank rows, cut and "
+                                        "filter counts) row-sharded with an all-gather of the per-row flags per scan, UPGMA "
+                                        "replicated, Part 2's chromosomes dealt to the ranks" % world) if args.shard_part1 else
+                                       ("ONE map over %d ranks: Part 1 on every rank (no collective), Part 2's chromosomes "
+                                        "dealt to the ranks, one all-gather of the ordered lists" % world)) if one_map
                                       else "1 independent map per rank, no collective" if world > 1 else "single GPU"},
             "roofline": roofline_of(timing, stats, steps, n, workers),
             "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in timing.items()
