@@ -1143,3 +1143,10 @@ def test_scan_loops_on_the_device_synthetic_maps(hic, monkeypatch, capsys, n, se
     both = _scan_loops_both_ways(hic, c, monkeypatch, capsys, 5, .05, .05, cuts_for_filter=dense)
     assert both["device"] == both["host"]
     assert 0 < len(both["host"][1]) < len(dense)
+    if n == 8000:
+        # more candidates than k_filter_decide keeps in LDS (2,048): its lists are walked in global memory
+        very_dense = list(range(6, n - 6, 3))
+        assert len(very_dense) > 2048
+        both = _scan_loops_both_ways(hic, c, monkeypatch, capsys, 5, .05, .05, cuts_for_filter=very_dense)
+        assert both["device"] == both["host"]
+        assert 0 < len(both["host"][1]) < len(very_dense)
