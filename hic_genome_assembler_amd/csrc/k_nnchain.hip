@@ -1932,6 +1932,12 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     const bool plain = getenv("HICMI_NNCHAIN_PLAIN") != nullptr;
     const bool fused1 = getenv("HICMI_NNCHAIN_FUSED1") != nullptr;       // narrow epochs on k_nn_epoch_mwc<1> instead of k_nn_epoch_nc
     const bool mw_old = getenv("HICMI_NNCHAIN_MW_OLD") != nullptr;       // k_nn_epoch_mw also where k_nn_epoch_mwc would fit (A/B, tests)
+    // Rebuild the whole cache (k_nn_rowmin, a full-chip pass over the flushed matrix: 0.13 ms at 8,000 live columns) before
+    // every epoch that has at most this many live columns: rows whose neighbour merged are then known again without a scan
+    // of their own.  Worth 1.5 ms per 16k map (scans per merge 1.28 -> 1.23: most such rows are walked within the epoch that
+    // invalidated them); above ~12,000 columns the pass costs more than the scans it saves.  0 = never.
+    const char* refresh_text = getenv("HICMI_NNCHAIN_REFRESH");
+    const int refresh_below = refresh_text ? atoi(refresh_text) : 8000;
     const bool force_gsize = getenv("HICMI_NNCHAIN_GSIZE") != nullptr;   // the GSIZE variant of k_nn_epoch_mwc at every width (tests)
     const int gsize_max = (n > NN_MWC_MAX || force_gsize) ? mwc_gsize_max_columns() : 0;
     if (dcap < 1) dcap = 1;
@@ -1974,7 +1980,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
         const bool gsize = wgs_e >= 8 && (n_cur > NN_MWC_MAX || force_gsize) && n_cur <= gsize_max;
         if (sliced && !plain && !mw_old && (n_cur <= NN_MWC_MAX || gsize)) {
             // column slices + neighbour cache + the next scan fused into the update (k_nn_epoch_mwc)
-            if (!cache_valid) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
+            if (!cache_valid || (refresh_below > 0 && n_cur <= refresh_below)) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
             cache_valid = true;
             const size_t lds_c = align16((size_t)nw4 * 12 + (size_t)((n_cur + 7) & ~7) * (gsize ? 2 : 4));
             hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 1152, s);      // mailboxes
@@ -1991,14 +1997,14 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
         }
         else if (!plain && fused1 && n_cur <= NN_MWC_MAX) {
             // one workgroup, but the fused pass of k_nn_epoch_mwc (its exchange degenerates to a store nobody waits for)
-            if (!cache_valid) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
+            if (!cache_valid || (refresh_below > 0 && n_cur <= refresh_below)) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
             cache_valid = true;
             const size_t lds_c = align16((size_t)nw4 * 12 + (size_t)((n_cur + 7) & ~7) * 4);
             hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 1152, s);
             launch_mwc(1, profile, lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
         }
         else if (!plain && n_cur <= NN_NC_MAX) {
-            if (!cache_valid) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
+            if (!cache_valid || (refresh_below > 0 && n_cur <= refresh_below)) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
             cache_valid = true;
             const size_t lds_nc = align16((size_t)nw4 * 12 + (size_t)((n_cur + 7) & ~7) * 4);
             if (profile) hipLaunchKernelGGL(k_nn_epoch_nc<true>, dim3(1), dim3(NN_THREADS), lds_nc, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
