@@ -164,11 +164,13 @@ def test_upgma_cluster_sizes_in_global_memory_bit_exact(hic, orc, monkeypatch, n
     assert np.array_equal(leaves, leaves_o)
 
 
-def test_upgma_wide_rows_cached_and_uncached_agree_at_40k(hic, monkeypatch):
+def test_upgma_wide_rows_cached_and_uncached_agree_at_40k(hic, orc, monkeypatch):
     """40,000 bins: the first epochs have more than 32,768 live columns and run on the GSIZE variant of the cached
     kernel; HICMI_NNCHAIN_MW_OLD=1 runs them on k_nn_epoch_mw (no cache: the round-1 kernel the 64k tests of round 1
     pinned).  Same merges, and fewer row scans (on uniform random distances the cache saves far less than on Hi-C maps:
-    2.3 scans per merge against 2.9; the 64k bench map runs at 1.28)."""
+    2.3 scans per merge against 2.9; the 64k bench map runs at 1.28).  The default run is also compared with the CPU
+    oracle's nn-chain (~1.5 min of host time): what every 64,000-bin map starts on is pinned at its own width, not only
+    when forced onto small inputs."""
     import torch
     n = 40000
     g = torch.Generator(device="cuda:0")
@@ -189,6 +191,18 @@ def test_upgma_wide_rows_cached_and_uncached_agree_at_40k(hic, monkeypatch):
     assert np.array_equal(got[0][0], got[1][0])
     assert sorted(got[0][0].tolist()) == list(range(n))
     assert got[0][2]["scans"] < 0.85 * got[1][2]["scans"]
+    host = c.cpu().numpy()
+    del c
+    torch.cuda.empty_cache()
+    dist = np.empty((n, n), np.float64)
+    for r0 in range(0, n, 2048):                            # orc.to_distance (S2C:147) in row blocks
+        blk = host[r0:r0 + 2048]
+        dist[r0:r0 + 2048] = (1.0 - (blk / orc.np_row_sums(blk)[:, None])) + 1.0
+    del host
+    zraw_o = orc.nn_chain_raw(dist)
+    del dist
+    assert np.array_equal(got[0][1], zraw_o)
+    assert np.array_equal(got[0][0], orc.leaf_order(orc.label_linkage(zraw_o, n), n))
 
 
 def test_upgma_column_sliced_chain_default_width_at_scale(hic, orc):

@@ -1,7 +1,10 @@
 """The BASELINE.json sizes themselves (configs[1]-[4]) on one MI355X.
 
 * 16,000 bins: Part 1 of the very step bench.py times against the CPU oracle - four files byte for byte
-  (configs[1]/[2]; the oracle's SciPy linkage + NumPy argsort + hypergeometric scans take a minute or two).
+  (configs[1]/[2]; the oracle's SciPy linkage + NumPy argsort + hypergeometric scans take a minute or two); Part 2 of
+  configs[2] through fixed-point properties and file equality with the earlier implementations.
+* 32,000 bins: the UPGMA tree, leaf order, sampled rank rows and first-scan counts against the CPU oracle
+  (north_star's Target size).
 * 32,000 bins (configs[3]'s map, north_star's single-GPU target) and 64,000 bins with fp32 contacts
   (configs[4]'s map): the WHOLE resident -part1 -part2, stage by stage, through properties no oracle is needed for -
   leaf order a permutation, heights sorted, rank rows the inverse of the rank matrix and descending in similarity,
@@ -67,6 +70,133 @@ def test_part1_matches_oracle_at_16000_bins(tmp_path):
     assert list(cuts_g) == list(cuts_o) and len(cuts_g) >= 10
     for a, b in zip(fg, fo):
         assert open(a).read() == open(b).read(), a
+
+
+def _check_part2_fixed_points(ctx, p2, gm, kept_bins, ordered, min_checked):
+    """Part 2 (a-13..a-15) without an oracle: every ordered chromosome with more than nScaffolds scaffolds is a fixed
+    point of scanOrdering (OG:519-544) under its literal score, and the closed-form score agrees with the literal one."""
+    checked = 0
+    with contextlib.redirect_stdout(io.StringIO()):
+        for group in ordered:
+            if len(group) <= 6:
+                continue
+            view, _od = p2.giveNewAdjMat(gm, group, kept_bins)
+            total = view.total()
+            ids, rev = view.layout.describe(group)
+            row = view.layout.node_row(ids, rev)
+            exact = float(ctx.p2_score_exact(row[None, :], total)[0])
+            fast = float(ctx.p2_score(row[None, :], total)[0])
+            assert abs(fast - exact) <= 1e-10 * abs(exact)                      # north_star asks for 1e-5
+            view.layout.tables(5)
+            floor = exact * (1.0 + 1e-15)         # `total` was rounded in another order during the search
+            _i, _r, best2, _cf, improved = ctx.p2_scan_pass(ids, rev, 5, total, floor, None)
+            assert not improved and best2 == floor
+            gm.chrom = None
+            checked += 1
+    assert checked >= min_checked
+    return checked
+
+
+def test_part2_at_16000_bins(tmp_path):
+    """BASELINE configs[2]'s Part 2 half (OG:608-612 on the 16,000-bin map of bench.py's default step, which the oracle
+    cannot order in test time: its brute force alone is 23,040 literal costs of ~10^6 terms per chromosome).  Asserted
+    instead: every ordered chromosome is a fixed point of the sliding-window search under its literal score, the closed
+    form agrees with the literal score to 1e-10, the files are consistent with each other, and the six files equal those
+    of the earlier implementations of every stage (host-decided insertion, per-candidate window kernels, one queue per
+    chromosome, cache-less single-workgroup nn-chain, radix sort) run in a second process."""
+    import torch
+    from hic_genome_assembler_amd import _lib, orderGenome as p2, scaffoldToChromosomes as p1, synth
+    from hic_genome_assembler_amd.hostio import Bin
+    n, seed = 16000, 1
+    lay = synth.make_layout(n, seed=seed)
+    ct = synth.dense_contacts_torch(lay, torch.device("cuda", 0), seed=seed, sinkhorn_iters=8)      # = _resident_map(n, 1, False)
+    torch.cuda.synchronize()
+    out = tmp_path / "default"
+    out.mkdir()
+    sizes = _sizes_file(lay, out / "sizes.txt")
+    f = lambda k: str(out / k)  # noqa: E731
+    with _lib.Context(0) as ctx:
+        ctx.set_contacts_device(ct.data_ptr(), n, keepalive=ct)
+        dm = p1.DeviceMatrix(ctx)
+        with contextlib.redirect_stdout(io.StringIO()):
+            p1.runResident(dm, _bins(lay, Bin), sizes, *[f(k) for k in FILES[:4]], 5, 0.0, .05)
+            gm = p2.GenomeMatrix(ctx)
+            ordered = p2.runResident(gm, dm.kept_bins, f(FILES[3]), f(FILES[4]), f(FILES[5]), 6, 5, lay.resolution)
+        grouped = [l.split("\t")[0] for l in open(f(FILES[3])).read().splitlines() if not l.startswith("#")]
+        plotted = [l.split("\t")[1] for l in open(f(FILES[5])).read().split("\n")[1:]]
+        assert sorted(grouped) == sorted(plotted) and len(set(plotted)) == len(plotted)
+        assert len(ordered) >= len(set(lay.chrom_of_bin.tolist()))
+        _check_part2_fixed_points(ctx, p2, gm, dm.kept_bins, ordered, 8)
+    texts = {k: open(f(k)).read() for k in FILES}
+    assert texts["chromosomeOrders.txt"].count("\n") > n // 20
+    del ct
+    torch.cuda.empty_cache()
+    script = tmp_path / "variant.py"
+    script.write_text(_VARIANT_RUN)
+    alt = tmp_path / "earlier"
+    alt.mkdir()
+    res = subprocess.run([sys.executable, str(script), ROOT, str(n), str(seed), "0", str(alt)],
+                         env=dict(os.environ, **_EARLIER), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    for k in FILES:
+        assert open(alt / k).read() == texts[k], k
+
+
+def _oracle_distance_blocked(orc, c, block=2048):
+    """orc.to_distance (S2C:147) in row blocks: the same three roundings per element without three N x N temporaries."""
+    n = c.shape[0]
+    out = np.empty((n, n), np.float64)
+    for r0 in range(0, n, block):
+        blk = c[r0:r0 + block]
+        sig = orc.np_row_sums(blk)
+        out[r0:r0 + block] = (1.0 - (blk / sig[:, None])) + 1.0
+    return out
+
+
+def test_upgma_matches_oracle_at_32000_bins():
+    """north_star's Target size ("32,000 x 32,000 ... cluster/order outputs identical to the CPU reference"): the map of
+    bench.py's north_star_32k object (seed 1), default kernels, against the CPU oracle - the raw merges in merge order,
+    the labelled linkage, the leaf order (S2C:194-204) bit for bit; then, for sampled rows of the reordered matrix, the rank
+    row against numpy's stable argsort (reversed) of the oracle's similarity row (S2C:149, 157-163, 1132) and the first
+    first-pass scan's count x_i (S2C:455-459) re-derived from it.  The oracle's nn-chain takes ~30-40 s of host time here."""
+    import time
+    import torch
+    import hic_oracle as orc
+    from hic_genome_assembler_amd import _lib, synth
+    n = 32000
+    lay = synth.make_layout(n, seed=1)
+    ct = synth.dense_contacts_torch(lay, torch.device("cuda", 0), seed=1, sinkhorn_iters=12)        # bench.py's Job(32000)
+    torch.cuda.synchronize()
+    with _lib.Context(0) as ctx:
+        ctx.set_contacts_device(ct.data_ptr(), n, keepalive=ct)
+        _np_sum, seq = ctx.row_sums()
+        leaves, z = ctx.upgma()
+        zraw = ctx.raw_merges()
+        c = ct.cpu().numpy()
+        t0 = time.time()
+        dist = _oracle_distance_blocked(orc, c)
+        zraw_o = orc.nn_chain_raw(dist)
+        z_o = orc.label_linkage(zraw_o, n)
+        leaves_o = orc.leaf_order(z_o, n)
+        print("oracle UPGMA at 32,000 bins: %.1f s" % (time.time() - t0))
+        assert np.array_equal(zraw, zraw_o)
+        assert np.array_equal(z, z_o)
+        assert np.array_equal(leaves, leaves_o)
+        # ---- rank rows and first-scan counts of sampled rows against the oracle's similarity rows
+        ctx.rank_matrix(leaves)
+        _sig, x = ctx.cut_scan(0, n, 0.05, want_x=True)
+        rng = np.random.default_rng(32)
+        order = leaves_o.astype(np.int64)
+        for a in [0, 1, 2, n // 2, n - 2, n - 1] + rng.integers(0, n, 42).tolist():
+            r = int(order[a])
+            assert seq[r] == orc.seq_row_sums(c[r:r + 1])[0]
+            sim = seq[r] * (1.0 - (dist[r][order] - 1.0))                          # S2C:149 on the reordered row (S2C:161)
+            R_o = np.argsort(sim, kind="stable")[::-1]
+            assert np.array_equal(ctx.similarity_row(a), sim)
+            assert np.array_equal(ctx.rank_rows(a, 1)[0].astype(np.int64), R_o), a
+            if a > 0:
+                pr = R_o[:a]
+                assert x[a] == np.count_nonzero((pr >= 0) & (pr <= a)), a
 
 
 # ------------------------------------------------------------------------------------------------ 32k / 64k
@@ -151,27 +281,8 @@ def _check_stages_and_run(hic, lay, contacts, out_dir):
         plotted = [l.split("\t")[1] for l in open(f(FILES[5])).read().split("\n")[1:]]
         assert sorted(grouped) == sorted(plotted) and len(set(plotted)) == len(plotted)
         assert len(ordered) >= len(set(lay.chrom_of_bin.tolist()))
-        # planted chromosomes: a scaffold's neighbours in the final order are its planted neighbours, mostly
         # ---- Part 2 (a-13..a-15): every chromosome is a fixed point of scanOrdering under its literal score
-        checked = 0
-        with contextlib.redirect_stdout(io.StringIO()):
-            for group in ordered:
-                if len(group) <= 6:
-                    continue
-                view, _od = p2.giveNewAdjMat(gm, group, dm.kept_bins)
-                total = view.total()
-                ids, rev = view.layout.describe(group)
-                row = view.layout.node_row(ids, rev)
-                exact = float(ctx.p2_score_exact(row[None, :], total)[0])
-                fast = float(ctx.p2_score(row[None, :], total)[0])
-                assert abs(fast - exact) <= 1e-10 * abs(exact)                      # north_star asks for 1e-5
-                view.layout.tables(5)
-                floor = exact * (1.0 + 1e-15)         # `total` was rounded in another order during the search
-                _i, _r, best2, _cf, improved = ctx.p2_scan_pass(ids, rev, 5, total, floor, None)
-                assert not improved and best2 == floor
-                gm.chrom = None
-                checked += 1
-        assert checked >= 8
+        _check_part2_fixed_points(ctx, p2, gm, dm.kept_bins, ordered, 8)
     return {k: open(f(k)).read() for k in FILES}
 
 
