@@ -586,7 +586,7 @@ static int ensure_rank_buffers(hicmi_ctx* c, int64_t n, int64_t ldr, bool bitoni
 // similarities inside a row.  A row without equal similarities has the same sorted sequence under any numbering, so its
 // rank row in leaf labels is the rank row in storage labels re-addressed: rank[a][b] = rank_s[order[a]][order[b]].
 // While the chain runs on the main stream, a second low-priority stream therefore sorts every row in storage labels
-// (same kernel, identity order, on at most 224 CUs so that the chain's workgroups and its flush kernels always find a
+// (same kernel, identity order, on at most 192 CUs so that the chain's workgroups and its flush kernels always find a
 // free one) and notes which rows hold equal keys, and where; hicmi_rank_matrix then only relabels (k_rank_relabel, ~0.5 ms
 // at 16k), and finishes the rows with equal keys (sparse maps, fp32 contacts: possibly all of them) with a sort of
 // 32-bit (run, leaf position) keys - k_sort_tied.hip.  HICMI_NO_PRESORT=1 disables.
@@ -645,7 +645,7 @@ static int start_presort(hicmi_ctx* c)
         x.tie_count = reinterpret_cast<unsigned*>(c->d_ties); x.tie_flag = c->d_ties + 16;
         x.tie_limit = (unsigned)n;                                 // (never gives up: tied rows are finished by k_rank_rows_tied)
         x.tie_bits = c->d_tie_bits; x.ld_bits = ld_bits;
-        x.max_workgroups = 224;
+        x.max_workgroups = 192;                                    // (the chain: up to 64 single-wave workgroups, one CU each)
         launch_sort_rows(c->dC, c->ldc, c->d_ident, c->d_ident, c->d_np, c->d_seq, (int)n, c->d_sort_scratch, c->dR, ldr, 0, 1,
                          c->stream2, x);
         launch_rank_invert(c->dR, c->dRankS, ldr, (int)n, 0, 1, c->stream2);
@@ -675,7 +675,7 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         free_dev(c->d_size); free_dev(c->d_chain); free_dev(c->d_zraw); free_dev(c->d_status);
         c->d_size = c->d_chain = c->d_status = nullptr; c->d_zraw = nullptr;
         HIPCHK(hipMalloc((void**)&c->d_size, nnchain_workspace_bytes((int)n)));
-        HIPCHK(hipMalloc((void**)&c->d_chain, sizeof(int) * 16 * (size_t)(n + 2)));     // one copy per workgroup of k_nn_epoch_mw / _mwc
+        HIPCHK(hipMalloc((void**)&c->d_chain, sizeof(int) * 64 * (size_t)(n + 2)));     // one copy per workgroup of k_nn_epoch_w1 (64) / _mw / _mwc (16)
         HIPCHK(hipMalloc((void**)&c->d_zraw, sizeof(double) * 4 * (size_t)n));
         HIPCHK(hipMalloc((void**)&c->d_status, sizeof(int)));
     }

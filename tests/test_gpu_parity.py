@@ -142,6 +142,76 @@ def test_upgma_column_sliced_chain_bit_exact(hic, orc, monkeypatch, n, seed, dca
     assert np.array_equal(leaves, leaves_o)
 
 
+@pytest.mark.parametrize("slices", [1, 2, 3, 7, 16, 33, 64])
+@pytest.mark.parametrize("n,seed,dcap", [(2, 0, 256), (3, 1, 1), (130, 1, 7), (600, 2, 64), (1025, 6, 256), (2500, 7, 256), (4099, 8, 100)])
+def test_upgma_one_wave_per_slice_bit_exact(hic, orc, monkeypatch, n, seed, dcap, slices):
+    """k_nn_epoch_w1 (round 3, the default up to 32,768 live columns): the chain as up to 64 single-wave workgroups that each
+    stream a slice of the columns, reduce in the wave (no workgroup barrier), exchange (min, index, tie) once per merge and
+    keep the neighbour cache with time stamps instead of an eager invalidation pass.  HICMI_NNCHAIN_W1_S forces the number
+    of slices for every epoch (the plan widens a slice to at most 2,048 columns and drops empty ones), HICMI_NNCHAIN_DCAP the
+    flush period.  Against the oracle's raw merges and leaf order on random distances (three runs: the exchange is
+    timing-dependent, the linkage must not be) and on tie-heavy integer distances."""
+    monkeypatch.setenv("HICMI_NNCHAIN_W1_S", str(slices))
+    monkeypatch.setenv("HICMI_NNCHAIN_DCAP", str(dcap))
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, n)) + 0.01
+    c = c + c.T
+    for _ in range(3 if n <= 1025 else 2):
+        leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, c)
+        assert np.array_equal(zraw, zraw_o)
+        assert np.array_equal(leaves, leaves_o)
+    ties = rng.integers(1, 4, size=(n, n)).astype(np.float64)
+    ties = np.triu(ties, 1) + np.triu(ties, 1).T + np.eye(n)
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, ties)
+    assert np.array_equal(zraw, zraw_o)
+    assert np.array_equal(leaves, leaves_o)
+
+
+@pytest.mark.parametrize("cols", [64, 128, 1024, 2048])
+def test_upgma_one_wave_per_slice_planned_widths(hic, orc, monkeypatch, cols):
+    """The plan itself (HICMI_NNCHAIN_W1_COLS columns per slice: 1, 2, 8 or 16 pairs per lane and streamed row) on a Hi-C-like
+    map with planted chromosomes and on its quantised, sparse twin (exact ties in every row: the cache must defer to scans)."""
+    from hic_genome_assembler_amd import synth
+    monkeypatch.setenv("HICMI_NNCHAIN_W1_COLS", str(cols))
+    lay = synth.make_layout(3000, seed=7)
+    c = synth.dense_contacts(lay, seed=7, sinkhorn_iters=8)
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, c)
+    assert np.array_equal(zraw, zraw_o) and np.array_equal(z, z_o) and np.array_equal(leaves, leaves_o)
+    q = np.round(c, 1)
+    q[q <= np.quantile(q, 0.4)] = 0.0
+    q = 0.5 * (q + q.T)
+    np.fill_diagonal(q, np.maximum(np.diag(q), 1.0))
+    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, np.ascontiguousarray(q))
+    assert np.array_equal(zraw, zraw_o) and np.array_equal(leaves, leaves_o)
+
+
+def test_upgma_one_wave_per_slice_late_peer_and_divergence(hic, orc, monkeypatch, capfd):
+    """The safety nets on the one-wave kernel: an exchange declared late (test hook) re-runs the map on one workgroup;
+    a replica whose merge record differs (test hook: replica 1 flips a bit of the height of merge 123 in its hash) fails the
+    call instead of returning a tree."""
+    monkeypatch.setenv("HICMI_NNCHAIN_W1_S", "5")
+    monkeypatch.setenv("HICMI_NNCHAIN_TEST_LATE", "40")
+    rng = np.random.default_rng(12)
+    n = 700
+    c = rng.random((n, n)) + 0.01
+    c = c + c.T
+    dist = orc.to_distance(c)
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(c)
+        ctx.timing_reset()
+        leaves, _z = ctx.upgma()
+        assert ctx.nnchain_stats()["retries"] == 1
+        assert np.array_equal(ctx.raw_merges(), orc.nn_chain_raw(dist))
+        assert "answered late" in capfd.readouterr().err
+        monkeypatch.delenv("HICMI_NNCHAIN_TEST_LATE")
+        monkeypatch.setenv("HICMI_NNCHAIN_TEST_DIVERGE", "123")
+        with pytest.raises(hic.HicmiError, match="replicas"):
+            ctx.upgma()
+        monkeypatch.delenv("HICMI_NNCHAIN_TEST_DIVERGE")
+        leaves, _z = ctx.upgma()                       # the context is usable afterwards
+        assert np.array_equal(leaves, orc.average_cluster_leaves(dist)[0])
+
+
 @pytest.mark.parametrize("n,seed,dcap", [(130, 1, 7), (1025, 6, 256), (4099, 8, 300)])
 def test_upgma_cluster_sizes_in_global_memory_bit_exact(hic, orc, monkeypatch, n, seed, dcap):
     """k_nn_epoch_mwc<8, ., true>: what rows beyond 32,768 columns run on - the neighbour cache alone in LDS, the cluster
