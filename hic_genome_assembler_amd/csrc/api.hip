@@ -733,6 +733,9 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
             fprintf(stderr, "[hicmi] fused pass detail (ms): issue gathers %.2f, LDS pass %.2f, loads arrive %.2f, compute+stores %.2f, "
                             "gathered+reductions %.2f, stores acked %.2f, barrier %.2f\n",
                     dq[0] / 1e5, dq[1] / 1e5, dq[2] / 1e5, dq[3] / 1e5, dq[4] / 1e5, dq[5] / 1e5, dq[6] / 1e5);
+        if (dq[9])
+            fprintf(stderr, "[hicmi] one-wave kernel: %llu exchanges, post + polling %.2f ms, %.2f polls of the slowest peer per exchange\n",
+                    dq[9], dq[8] / 1e5, (double)dq[10] / (double)dq[9]);
     }
     if (nn.state[5] == 2)
         return fail(HICMI_ESTATE, "nn-chain: a peer workgroup of the column-sliced kernel answered late, and so did the retry");
@@ -740,8 +743,8 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         return fail(HICMI_ESTATE, "nn-chain: the replicas of the column-sliced kernel disagree about a merge (stale read between "
                                   "workgroups); set HICMI_NNCHAIN_WGS=1 to run on one workgroup");
     if (nn.state[5] != 0 || nn.state[0] != (int)(n - 1))
-        return fail(HICMI_ESTATE, "nn-chain kernel stopped on its guard at merge %d of %lld (NaN distances or an internal error)",
-                    nn.state[0], (long long)(n - 1));
+        return fail(HICMI_ESTATE, "nn-chain kernel stopped on its guard at merge %d of %lld (NaN distances or an internal error; check %d)",
+                    nn.state[0], (long long)(n - 1), nn.state[13]);
     std::vector<double> Z((size_t)(4 * (n - 1)));
     rc = hicmi_label_linkage(c->zraw.data(), n, Z.data());
     if (rc) return rc;

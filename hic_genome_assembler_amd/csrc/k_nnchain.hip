@@ -223,7 +223,8 @@ struct NNWorkspace {
     double* rec;                // NN_MAXWG x NN_DMAX x 4: the merges of the last epoch as every replica of k_nn_epoch_mw saw them
     int* size_rep;              // NN_W1_MAXS x n: cluster sizes, one private copy per replica of k_nn_epoch_w1 and of
                                 // k_nn_epoch_mwc<.., .., true> (rows beyond 32,768 columns: the sizes do not fit the LDS beside the cache)
-    void* mailw;                // k_nn_epoch_w1: NN_W1_MAIL bytes of mailboxes, then NN_W1_MAXS 8-byte merge-record hashes
+    void* mailw;                // k_nn_epoch_w1: NN_W1_MAIL bytes of mailboxes, then NN_W1_MAXS 8-byte merge-record hashes, then 16 bytes
+                                // per lane and replica where the stores of masked-out elements land
 };
 static constexpr int NN_STOP_GUARD = 1, NN_STOP_LATE = 2, NN_STOP_DIVERGED = 3;
 static constexpr uint32_t NN_NOIDX = 0xffffu;
@@ -235,7 +236,7 @@ size_t nnchain_workspace_bytes(int n)
     size_t nwords = (size_t)(n + 31) / 32;
     return NN_HEAD + align16(nwords * 4) + align16((size_t)n * 2) + 4 * align16((size_t)n * 4) + 2 * align16(NN_DMAX * 4) +
            align16((size_t)n * 8) + align16((size_t)n * 4) + (size_t)NN_MAXWG * NN_DMAX * 4 * 8 +
-           (size_t)NN_W1_MAXS * align16((size_t)n * 4) + NN_W1_MAIL + NN_W1_MAXS * 8;
+           (size_t)NN_W1_MAXS * align16((size_t)n * 4) + NN_W1_MAIL + NN_W1_MAXS * 8 + NN_W1_MAXS * 64 * 16;
 }
 
 static NNWorkspace carve(void* ws, int n)
@@ -802,9 +803,12 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_nc(double* __restrict__
 // next scan visits - is handed from the owner of column z (which computes it in its update) to the owner of
 // column y' (the only reader: it lists y' among its dirty candidates) through a tagged 16-byte slot of its own.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// (s_nop: a vector-memory store of more than 64 bits must not be followed at once by a vector instruction that overwrites
+//  its data registers; the compiler pads its own stores, but it does not look inside inline assembly - seen as wrong
+//  bytes in the stored row when the next instruction was an address computation into the same registers)
 __device__ __forceinline__ void st16_sc1(void* p, u32x4 v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ u32x4 ld16_sc1(const void* p)
 {
@@ -1742,21 +1746,28 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
 // one lane's serial bookkeeping while fifteen waves wait, and an LDS pass of all 1024 lanes over the whole neighbour
 // cache.  Here a slice is ONE wave (a 64-lane workgroup, up to 64 of them, one per CU):
 //  * no workgroup barrier anywhere: reductions are DPP-only (argmint_wave_fast), the exchange is polled by one lane
-//    per peer and reduced in the wave, every lane carries the (uniform) chain state itself;
+//    per peer and reduced in the wave, every lane carries the (uniform) chain state itself - in scalar registers;
 //  * every load of a pass - up to TRIPS 16-byte pairs per streamed row and lane, the gathered values, the two cluster
 //    sizes - is in flight before anything waits; the cached distances of the own columns live in LDS;
-//  * the neighbour cache is invalidated LAZILY: an entry carries the epoch-local time it was written at (idx | tie << 16
-//    | stamp << 17); it is valid iff its slot is alive and has not merged since (dirty-list time <= stamp).  The eager
-//    LDS pass over all n entries per merge is gone; k_nn_settle turns the entries back into the stamp-free form between
-//    epochs;
-//  * the dirty list (<= 256 entries: 4 per lane) lives in registers; cluster sizes in a private global array per replica
-//    (two loads per merge, issued with the row loads); the replicas' merge records are compared as one running hash per
-//    replica (k_nn_check_hashes) instead of 4 stores per merge and replica.
+//  * ONE 32-bit word per slot holds everything the serial part of a merge asks about it:
+//        idx (15 bits, 0x7fff = unknown) | tie << 15 | stamp << 16 | mtime << 24
+//    the cached nearest slot and its tie flag, the epoch-local time the entry was written at, and the time the slot
+//    itself last merged (0 = not in this epoch, 255 = dead).  The cache is invalidated LAZILY: an entry is valid iff
+//    mtime[idx] != 255 and mtime[idx] <= stamp - two dependent LDS reads per chain step, no bitmaps, no eager pass over
+//    all n entries per merge.  k_nn_settle turns the entries back into the stamp-free form between epochs;
+//  * NO deferred column writes: with up to 64 workgroups at work the column half of a merge is a handful of scattered
+//    8-byte stores per lane (the owner of column j writes W[y'][j] AND W[j][y']), so the matrix stays symmetric and
+//    current - no dirty list, no gathered partner values, no "which row is authoritative" logic, no flush kernel;
+//  * a single wave issues one instruction every ~4-5 cycles whatever it is, so the serial part is written for instruction
+//    count: select-based arg-min updates instead of branches, cluster sizes in a private global array per replica (two
+//    loads per merge, issued with the row loads), the replicas' merge records compared as one running hash per replica
+//    (k_nn_check_hashes) instead of 4 stores per merge and replica.
 // Visibility between the workgroups is the protocol of k_nn_epoch_mw / _mwc unchanged (sc1 stores and loads of every
 // matrix byte, stores drained before the mailbox store, bounded spins, double-buffered 16-byte slots that carry their
 // sequence number in both halves).
-static constexpr int NN_W1_DCH = 4;                      // dirty entries per lane -> at most 256 merges per epoch
-static constexpr int NN_W1_MAX = 32768;                  // 4-byte cache entries of every column in the LDS of every replica
+static constexpr int NN_W1_DCAP = 252;                   // merges per epoch: 8-bit times
+static constexpr int NN_W1_MAX = 32767;                  // 15-bit slot numbers; one 4-byte word per column in the LDS of every replica
+static constexpr uint32_t W1_NOIDX = 0x7fffu;
 // Loads of this kernel are COMPILER-VISIBLE (its wait-count pass tracks them): the streamed pairs are raw buffer loads with
 // the sc1 bit (buffer_load_dwordx4 ... offen sc1; a row is one buffer resource, so lanes beyond the slice read zeros
 // instead of needing a branch), the gathered values and sizes relaxed agent-scope atomic loads (global_load ... sc1).
@@ -1781,29 +1792,58 @@ __device__ __forceinline__ void w1_poll(u32x4& a, u32x4& b, const u32x4* pa, con
     asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b) : "v"(pa), "v"(pb) : "memory");
 }
-
-__device__ __forceinline__ uint32_t w1_entry(int idx, int tie, int stamp)
-{
-    return (uint32_t)idx | ((uint32_t)(tie ? 1 : 0) << 16) | ((uint32_t)stamp << 17);
-}
 __device__ __forceinline__ void st4_sc1(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double bcast_f64(unsigned long long bits, int src)
 {
     return __hiloint2double(__builtin_amdgcn_readlane((int)(bits >> 32), src), __builtin_amdgcn_readlane((int)(bits & 0xffffffffull), src));
 }
+// streaming arg-min update without a branch: ascending j per lane, so the first of equal values stays and sets the tie flag
+__device__ __forceinline__ void w1_upd(ArgMinT& b, bool live, double v, int j)
+{
+    const bool lt = live && v < b.v, eq = live && v == b.v;
+    b.t = lt ? 0 : (eq ? 1 : b.t);
+    b.i = lt ? j : b.i;
+    b.v = lt ? v : b.v;
+}
+
+// Wave arg-min when the candidates' indices do not decrease with the lane (a lane owns a contiguous run of columns;
+// a peer owns a contiguous slice): the lowest index at the minimum is the lowest LANE at the minimum - one ballot instead
+// of a second DPP reduction.  Result uniform; i = 0x7fffffff when nothing compares (no candidates / NaN).
+__device__ __forceinline__ ArgMinT argmint_wave_mono(ArgMinT a)
+{
+    double m = a.v;
+    m = fmin_dpp_step<0xB1>(m); m = fmin_dpp_step<0x4E>(m); m = fmin_dpp_step<0x141>(m); m = fmin_dpp_step<0x140>(m);
+    const double mv = fmin(fmin(readlane_f64(m, 0), readlane_f64(m, 16)), fmin(readlane_f64(m, 32), readlane_f64(m, 48)));
+    const unsigned long long at = __ballot(a.v == mv && a.i != 0x7fffffff);
+    ArgMinT r = {mv, 0x7fffffff, 0};
+    if (at) {
+        const int l = (int)__ffsll((long long)at) - 1;
+        r.i = __builtin_amdgcn_readlane(a.i, l);
+        r.t = ((at & (at - 1ull)) != 0ull || __builtin_amdgcn_readlane(a.t, l) != 0) ? 1 : 0;
+    }
+    return r;
+}
+//   {value bits 31..0, seq} {value bits 63..32, index (15 bits, 0x7fff = none) | tie << 15 | event << 16 | (seq & 0x7fff) << 17}
+__device__ __forceinline__ u32x4 w1_mail(double v, int idx, int tie, int ev, unsigned int seq)
+{
+    u32x4 p;
+    p.x = (unsigned int)__double2loint(v); p.y = seq;
+    p.z = (unsigned int)__double2hiint(v);
+    p.w = ((unsigned int)((idx >= 0 && idx < 0x7fff) ? idx : 0x7fff)) | ((unsigned int)(tie ? 1 : 0) << 15) | ((unsigned int)(ev ? 1 : 0) << 16) |
+          ((seq & 0x7fffu) << 17);
+    return p;
+}
+__device__ __forceinline__ bool w1_mail_ready(u32x4 p, unsigned int seq) { return p.y == seq && (p.w >> 17) == (seq & 0x7fffu); }
 
 template <int TRIPS, bool PROF>
 __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int64_t ld, int n, int* __restrict__ chain_all,
                                                     double* __restrict__ zraw, NNWorkspace w, int dcap, int total_steps, int slice)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_nn[];
-    constexpr int DCH = NN_W1_DCH;
     const int S = (int)gridDim.x, wg = (int)blockIdx.x, lane = (int)threadIdx.x;
-    const int nwords = (n + 31) >> 5, nw4 = (nwords + 3) & ~3, n4 = (n + 3) & ~3;
-    uint32_t* alive = reinterpret_cast<uint32_t*>(smem_nn);
-    uint32_t* smask = alive + nw4;                           // alive AND not dirty: what the streaming passes visit
-    uint32_t* nn = smask + nw4;                              // neighbour cache: idx | tie << 16 | stamp << 17 (idx 0xffff = unknown)
-    double* nnv = reinterpret_cast<double*>(nn + n4);        // cached distances of the OWN columns (owner-private)
+    const int n4 = (n + 3) & ~3;
+    uint32_t* meta = reinterpret_cast<uint32_t*>(smem_nn);   // idx | tie << 15 | stamp << 16 | mtime << 24, every slot
+    double* nnv = reinterpret_cast<double*>(meta + n4);      // cached distances of the OWN columns (owner-private)
     __shared__ int ring[256];
 
     int step = w1_uni(w.state[0]);
@@ -1811,16 +1851,27 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
         if (lane == 0 && wg == 0) w.state[6] = 0;
         return;
     }
-    // slice: a multiple of 64 columns (mask words and 16-byte loads never straddle), at most 128 * TRIPS
+    // slice: a multiple of 64 columns (16-byte loads never straddle), at most 128 * TRIPS.  A lane owns the 2 * TRIPS
+    // consecutive columns from jl0 on (pair t: jl0 + 2t, jl0 + 2t + 1): indices ascend with the lane (argmint_wave_mono)
     const int c0 = wg * slice < n ? wg * slice : n;
     const int c1 = c0 + slice < n ? c0 + slice : n;
+    const int jl0 = c0 + 2 * TRIPS * lane;
+    double* dump = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(w.mailw) + NN_W1_MAIL + NN_W1_MAXS * 8) + ((int64_t)wg * 64 + lane) * 2;
     int* __restrict__ gsize = w.size_rep + (int64_t)wg * n4;
     int* __restrict__ chain = chain_all + (int64_t)wg * (n + 2);
     const int* __restrict__ chain0 = chain_all;              // chain prefix of the earlier epochs: workgroup 0's copy
     u32x4* mailw = reinterpret_cast<u32x4*>(w.mailw);
 
-    for (int i = lane; i < nwords; i += 64) { const uint32_t a = w.alive[i]; alive[i] = a; smask[i] = a; }
-    for (int i = lane; i < n; i += 64) { nn[i] = w.nnc[i]; st4_sc1(gsize + i, (int)w.size[i]); }
+    for (int i = lane; i < n4; i += 64) {
+        uint32_t m = 0xff000000u | W1_NOIDX;                 // (padding behind n: dead)
+        if (i < n) {
+            const uint32_t c = w.nnc[i];
+            const uint32_t idx = (c & 0xffffu) >= W1_NOIDX ? W1_NOIDX : (c & 0xffffu);
+            m = idx | (((c >> 16) & 1u) << 15) | (((w.alive[i >> 5] >> (i & 31)) & 1u) ? 0u : 0xff000000u);
+            st4_sc1(gsize + i, (int)w.size[i]);
+        }
+        meta[i] = m;
+    }
     for (int i = c0 + lane; i < c1; i += 64) nnv[i - c0] = w.nnval[i];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int len = w1_uni(w.state[1]), top = w1_uni(w.state[2]), second = w1_uni(w.state[3]), first_ptr = w1_uni(w.state[4]);
@@ -1831,36 +1882,23 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
     if (lane == 0 && wg == 0) w.state[9] = step0;
     __syncthreads();
 
-    int ds[DCH], dt[DCH];                                    // dirty list: entry k in lane k & 63, register k >> 6
-#pragma unroll
-    for (int u = 0; u < DCH; u++) { ds[u] = -1; dt[u] = 0; }
-    int tl = 0;                                              // merges of this epoch so far = dirty entries = the local clock
+    int tl = 0;                                              // merges of this epoch so far: the local clock
     int lowmark = len;                                       // chain entries below this are still the earlier epochs'
     unsigned int xseq = 0u;
-    int guard = 0, stop_code = 0;
+    int guard = 0, stop_code = 0, why = 0;                   // why: which check stopped the chain (diagnostics, state[13])
     unsigned long long hash = 0x243F6A8885A308D3ull;         // of this replica's merge records
     unsigned long long c_cols = 0, c_scans = 0, c_hits = 0;
     unsigned long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;   // PROF: walk, scan, exchange+after, merge book, issue, arrive, compute, reduce, drain, -
     const bool prof = PROF && wg == 0;
+    unsigned long long npolls = 0;                           // PROF: polls of the slowest-answering peer, summed over the exchanges (per lane)
 #define W1_STAMP(k) do { if (prof) { const unsigned long long t1_ = wall_clock64(); tp[k] += t1_ - t0; t0 = t1_; } } while (0)
 
-    // dirty time of a (uniform) slot, -1 = clean
-    auto dirty_time = [&](int slot) -> int {
-        int t = -1;
-#pragma unroll
-        for (int u = 0; u < DCH; u++) if (ds[u] == slot) t = dt[u];
-        const unsigned long long b = __ballot(t >= 0);
-        if (b == 0ull) return -1;
-        return __builtin_amdgcn_readlane(t, (int)__ffsll((long long)b) - 1);
-    };
-    auto bit_of = [&](const uint32_t* m, int i) -> bool { return ((m[i >> 5] >> (i & 31)) & 1u) != 0u; };
-    auto ubit_of = [&](const uint32_t* m, int i) -> bool { return ((w1_uni((int)m[i >> 5]) >> (i & 31)) & 1) != 0; };   // uniform i
-    auto entry_valid = [&](uint32_t e) -> bool {
-        const int idx = (int)(e & 0xffffu);
-        if (idx == (int)NN_NOIDX || idx >= n) return false;
-        if (!ubit_of(alive, idx)) return false;
-        if (ubit_of(smask, idx)) return true;                // clean: has not merged in this epoch
-        return dirty_time(idx) <= (int)(e >> 17);            // dirty: valid iff written after that merge
+    auto umeta = [&](int i) -> uint32_t { return (uint32_t)w1_uni((int)meta[i]); };       // uniform i
+    auto entry_valid = [&](uint32_t e) -> bool {             // uniform
+        const uint32_t idx = e & W1_NOIDX;
+        if (idx == W1_NOIDX || (int)idx >= n) return false;
+        const uint32_t mt = umeta((int)idx) >> 24;           // 255: dead; otherwise valid iff written after the slot's last merge
+        return mt != 255u && mt <= ((e >> 16) & 0xffu);
     };
     auto push = [&](int v) {
         if (lane == 0) { st4_sc1(chain + len, v); ring[len & 255] = v; }
@@ -1873,32 +1911,35 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
     // one exchange: slot 0 = (m0, event flag), slot 1 = m1 (when `two`); results uniform.  Returns 1 when a peer was late.
     auto exchange = [&](ArgMinT m0, int ev0, ArgMinT m1, bool two, ArgMinT& r0, ArgMinT& r1, unsigned long long& evm) -> int {
         xseq++;
-        u32x4* slots = mailw + (xseq & 1u) * (NN_W1_MAXS * 2);
-        if (lane == 0) st16_sc1(slots + wg * 2, mwc_pack(m0.v, m0.i, m0.t, ev0, xseq));
-        if (two && lane == 1) st16_sc1(slots + wg * 2 + 1, mwc_pack(m1.v, m1.i, m1.t, 0, xseq));
+        u32x4* slots = mailw + (xseq & 1u) * (NN_W1_MAXS * 2);       // [slot 0 of every workgroup][slot 1 of every workgroup]
+        if (lane == 0) st16_sc1(slots + wg, w1_mail(m0.v, m0.i, m0.t, ev0, xseq));
+        if (two && lane == 1) st16_sc1(slots + NN_W1_MAXS + wg, w1_mail(m1.v, m1.i, m1.t, 0, xseq));
         ArgMinT o0 = {__builtin_inf(), 0x7fffffff, 0}, o1 = {__builtin_inf(), 0x7fffffff, 0};
         int late = 0, evbit = 0;
         if (lane < S) {
             if (lane == wg) { o0 = m0; o1 = m1; evbit = ev0; }
             else {
                 u32x4 pa, pb;
-                const u32x4* sa = slots + lane * 2;
-                const u32x4* sb = sa + (two ? 1 : 0);
+                const u32x4* sa = slots + lane;
+                const u32x4* sb = sa + (two ? NN_W1_MAXS : 0);
                 w1_poll(pa, pb, sa, sb);
                 int budget = 1000000;
-                while (!(mwc_ready(pa, xseq) && mwc_ready(pb, xseq)) && --budget > 0) {
-                    __builtin_amdgcn_s_sleep(1);
+                while (!(w1_mail_ready(pa, xseq) && w1_mail_ready(pb, xseq)) && --budget > 0) {
+                    if (budget < 999990) __builtin_amdgcn_s_sleep(1);
                     w1_poll(pa, pb, sa, sb);
                 }
-                if (!(mwc_ready(pa, xseq) && mwc_ready(pb, xseq))) late = 1;
-                o0.v = mw_value(pa); o0.i = mwc_index(pa); o0.t = mwc_tie(pa); evbit = mwc_event(pa);
-                o1.v = mw_value(pb); o1.i = mwc_index(pb); o1.t = mwc_tie(pb);
+                if (PROF) npolls += (unsigned long long)(1000001 - budget);
+                if (!(w1_mail_ready(pa, xseq) && w1_mail_ready(pb, xseq))) late = 1;
+                const int ia = (int)(pa.w & 0x7fffu), ib = (int)(pb.w & 0x7fffu);
+                o0.v = mw_value(pa); o0.i = ia == 0x7fff ? 0x7fffffff : ia; o0.t = (int)((pa.w >> 15) & 1u); evbit = (int)((pa.w >> 16) & 1u);
+                o1.v = mw_value(pb); o1.i = ib == 0x7fff ? 0x7fffffff : ib; o1.t = (int)((pb.w >> 15) & 1u);
             }
         }
         if (inject_late > 0 && (int)xseq == inject_late) late = 1;       // test hook: a peer that never answers
+        W1_STAMP(9);                                                     // (PROF: post + polling, until every peer has answered)
         evm = __ballot(evbit != 0);
-        r0 = argmint_wave_fast(o0);
-        if (two) r1 = argmint_wave_fast(o1);
+        r0 = argmint_wave_mono(o0);                                      // a peer's columns lie below the next peer's
+        if (two) r1 = argmint_wave_mono(o1);
         return __any(late) ? 1 : 0;
     };
 
@@ -1909,12 +1950,16 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             // ---- walk the chain on cached neighbours (every lane, identical state -> identical walk)
             __syncthreads();
             if (len == 0) {
-                int wi = first_ptr >> 5;
-                uint32_t m = wi < nwords ? ((uint32_t)w1_uni((int)alive[wi]) & (0xffffffffu << (first_ptr & 31))) : 0u;
-                while (m == 0u && ++wi < nwords) m = (uint32_t)w1_uni((int)alive[wi]);
-                first_ptr = m ? wi * 32 + (__ffs((int)m) - 1) : n;
-                if (first_ptr >= n) { stop_code = NN_STOP_GUARD; }
+                int base = first_ptr & ~63, found = -1;
+                while (base < n && found < 0) {
+                    const int i = base + lane;
+                    const unsigned long long b = __ballot(i < n && i >= first_ptr && (meta[i] >> 24) != 255u);
+                    if (b) found = base + (int)__ffsll((long long)b) - 1;
+                    base += 64;
+                }
+                if (found < 0) { first_ptr = n; stop_code = NN_STOP_GUARD; why = 1; }
                 else {
+                    first_ptr = found;
                     if (lane == 0) { st4_sc1(chain, first_ptr); ring[0] = first_ptr; }
                     ring_lo = 0; top = first_ptr; second = -1; len = 1; lowmark = 0;
                 }
@@ -1922,83 +1967,58 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             act = stop_code ? 3 : 0;                         // 1: scan row `top`, 2: merge (top, second), 3: stop
             while (act == 0) {
                 const int prev = (len > 1) ? second : -1;
-                const uint32_t e = (uint32_t)w1_uni((int)nn[top]);
+                const uint32_t e = umeta(top);
                 if (!entry_valid(e)) act = 1;
-                else if ((int)(e & 0xffffu) == prev) act = 2;
-                else if (prev >= 0 && ((e >> 16) & 1u)) act = 1;             // an exact tie: the value decides
-                else if (++guard > 4 * n + 8) { stop_code = NN_STOP_GUARD; act = 3; }
-                else { push((int)(e & 0xffffu)); c_hits++; }
+                else if ((int)(e & W1_NOIDX) == prev) act = 2;
+                else if (prev >= 0 && ((e >> 15) & 1u)) act = 1;             // an exact tie: the value decides
+                else if (++guard > 4 * n + 8) { stop_code = NN_STOP_GUARD; act = 3; why = 2; }
+                else { push((int)(e & W1_NOIDX)); c_hits++; }
             }
             if (act != 1) break;
             // ---- a scan on its own: this slice of row x, then one exchange
             const int x = top, prev = (len > 1) ? second : -1;      // (uniform: the chain state lives in scalar registers)
             c_scans++; c_cols += (unsigned long long)(total_steps + 1 - step);
-            const int tx = dirty_time(x);
+            const uint32_t ex = umeta(x);
             W1_STAMP(0);
             const double* __restrict__ rowx = W + (int64_t)x * ld;
             const __amdgpu_buffer_rsrc_t bx = w1_row(rowx, (c1 + 1) & ~1);
-            unsigned long long r_dp = 0, r_cv[DCH];
-            int cd[DCH]; bool cmine[DCH];
-            const bool prev_clean = prev >= 0 && ubit_of(smask, prev);
-            if (lane == 63 && prev_clean) r_dp = w1_ld8(rowx + prev);
-#pragma unroll
-            for (int u = 0; u < DCH; u++) {
-                cd[u] = -1; cmine[u] = false; r_cv[u] = 0;
-                const int d = ds[u];
-                if (d >= 0 && d != x && bit_of(alive, d)) {
-                    const bool mine = d >= c0 && d < c1;
-                    if (mine || d == prev) {
-                        cd[u] = d; cmine[u] = mine;
-                        r_cv[u] = w1_ld8(dt[u] > tx ? W + (int64_t)d * ld + x : rowx + d);
-                    }
-                }
-            }
+            unsigned long long r_dp = 0;
+            if (lane == 63 && prev >= 0) r_dp = w1_ld8(rowx + prev);
             u32x4 q[TRIPS];
 #pragma unroll
-            for (int t = 0; t < TRIPS; t++) q[t] = w1_ld16(bx, (c0 + 128 * t + 2 * lane) * 8);
+            for (int t = 0; t < TRIPS; t++) q[t] = w1_ld16(bx, (jl0 + 2 * t) * 8);
             NN_FENCE();
             NN_KEEP(r_dp);
-#pragma unroll
-            for (int u = 0; u < DCH; u++) NN_KEEP(r_cv[u]);
 #pragma unroll
             for (int t = 0; t < TRIPS; t++) NN_KEEP(q[t]);
             ArgMinT best = {__builtin_inf(), 0x7fffffff, 0};
 #pragma unroll
             for (int t = 0; t < TRIPS; t++) {
-                const int j = c0 + 128 * t + 2 * lane;
-                if (j < c1) {
-                    const double2 v = mw_pair(q[t]);
-                    const uint32_t bits = smask[j >> 5] >> (j & 31);
-                    if ((bits & 1u) && j != x && v.x <= best.v) { if (v.x < best.v) { best.v = v.x; best.i = j; best.t = 0; } else best.t = 1; }
-                    if ((bits & 2u) && j + 1 != x && v.y <= best.v) { if (v.y < best.v) { best.v = v.y; best.i = j + 1; best.t = 0; } else best.t = 1; }
-                }
+                const int j = jl0 + 2 * t;
+                const int jj = j < c1 ? j : c0;              // lanes behind the slice read a valid word and ignore it
+                const double2 v = mw_pair(q[t]);
+                const uint2 m2 = *reinterpret_cast<const uint2*>(meta + jj);
+                w1_upd(best, j < c1 && (m2.x >> 24) != 255u && j != x, v.x, j);
+                w1_upd(best, j < c1 && (m2.y >> 24) != 255u && j + 1 != x, v.y, j + 1);
             }
-            unsigned long long dpbits = r_dp; bool has_dp = lane == 63 && prev_clean;
-#pragma unroll
-            for (int u = 0; u < DCH; u++) {
-                if (cd[u] >= 0) {
-                    if (cmine[u]) best = argmint_join(best, nn_f64(r_cv[u]), cd[u], 0);
-                    if (cd[u] == prev) { dpbits = r_cv[u]; has_dp = true; }
-                }
-            }
-            const unsigned long long dpb = __ballot(has_dp);
-            const double dprev = dpb ? bcast_f64(dpbits, (int)__ffsll((long long)dpb) - 1) : __builtin_inf();
-            best = argmint_wave_fast(best);
+            const double dprev = prev >= 0 ? bcast_f64(r_dp, 63) : __builtin_inf();
+            best = argmint_wave_mono(best);
             W1_STAMP(1);
             ArgMinT m, m_unused = {__builtin_inf(), 0x7fffffff, 0};
             unsigned long long evm_unused;
             const int late = exchange(best, 0, m_unused, false, m, m_unused, evm_unused);
             if (late) stop_code = NN_STOP_LATE;
-            else if (m.i < 0 || m.i >= n) stop_code = NN_STOP_GUARD;
+            else if (m.i < 0 || m.i >= n) { stop_code = NN_STOP_GUARD; why = 3; }
             else {
                 int y = m.i;
                 if (prev >= 0 && !(m.v < dprev)) y = prev;               // SciPy: the previous element wins unless STRICTLY closer
                 if (lane == 0) {
-                    nn[x] = w1_entry(y == prev && prev >= 0 ? prev : m.i, m.t, tl);   // reciprocal by the tie rule: let the walk see it
+                    // (reciprocal by the tie rule: the entry names prev, so that the walk sees the pair)
+                    meta[x] = (uint32_t)(y == prev && prev >= 0 ? prev : m.i) | ((uint32_t)(m.t ? 1 : 0) << 15) | ((uint32_t)tl << 16) | (ex & 0xff000000u);
                     if (x >= c0 && x < c1) nnv[x - c0] = m.v;            // the owner of column x keeps the distance
                 }
                 if (y != prev) {
-                    if (++guard > 4 * n + 8) stop_code = NN_STOP_GUARD;
+                    if (++guard > 4 * n + 8) { stop_code = NN_STOP_GUARD; why = 4; }
                     push(y);
                 }
             }
@@ -2009,7 +2029,7 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
         int mx = top, my = second;                              // (uniform)
         if (mx > my) { const int t = mx; mx = my; my = t; }
         len -= 2;
-        if (lane == 0) { alive[mx >> 5] &= ~(1u << (mx & 31)); smask[mx >> 5] &= ~(1u << (mx & 31)); }
+        if (lane == 0) meta[mx] = 0xff000000u | W1_NOIDX;       // x is dead
         if (len < lowmark) lowmark = len;
         {
             const int i1 = len - 1, i2 = len - 2;
@@ -2018,52 +2038,36 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
         }
         __syncthreads();
         int a = -1;
+        uint32_t ea = 0u;
         if (top >= 0) {
-            const uint32_t ea = (uint32_t)w1_uni((int)nn[top]);
-            if (!entry_valid(ea) || (int)(ea & 0xffffu) == my) a = top;
+            ea = umeta(top);
+            if (!entry_valid(ea) || (int)(ea & W1_NOIDX) == my) a = top;
         }
         const int aprev = (a >= 0 && len > 1) ? second : -1;
         if (a >= 0) { c_scans++; c_cols += (unsigned long long)(total_steps - step); }
-        const int tmx = dirty_time(mx), tmy = dirty_time(my), ta = a >= 0 ? dirty_time(a) : -1;
         W1_STAMP(3);
         ArgMinT R = {__builtin_inf(), 0x7fffffff, 0}, A = {__builtin_inf(), 0x7fffffff, 0};
         unsigned long long evm = 0ull;
-        double dprev = __builtin_inf(), fs = 0.0;
+        double dprev = __builtin_inf(), fs = 0.0, ya = __builtin_inf();
         {
             const double* __restrict__ rx = W + (int64_t)mx * ld;
             double* __restrict__ ry = W + (int64_t)my * ld;
             const double* __restrict__ ra = W + (int64_t)(a >= 0 ? a : mx) * ld;
-            // ---- issue every load: sizes, gathered values, the streamed pairs (nothing waits yet)
+            // ---- issue every load: sizes, the height, d(a, prev), the streamed pairs (nothing waits yet)
             const __amdgpu_buffer_rsrc_t bx = w1_row(rx, (c1 + 1) & ~1), by = w1_row(ry, (c1 + 1) & ~1), ba = w1_row(ra, (c1 + 1) & ~1);
             int r_nx = __hip_atomic_load(gsize + mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int r_ny = __hip_atomic_load(gsize + my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned long long r_h = 0, r_dp = 0, r_dxi[DCH], r_dyi[DCH], r_av[DCH];
-            // the merge height d(x, y): the row of whichever cluster merged last is the authoritative one
-            if (lane == 62) r_h = w1_ld8(tmx > tmy ? rx + my : ry + mx);
-            const bool aprev_clean = aprev >= 0 && ubit_of(smask, aprev);
-            if (lane == 63 && aprev_clean) r_dp = w1_ld8(ra + aprev);
-            int dd[DCH], ad[DCH]; bool amine[DCH];
-#pragma unroll
-            for (int u = 0; u < DCH; u++) {
-                dd[u] = -1; ad[u] = -1; amine[u] = false; r_dxi[u] = 0; r_dyi[u] = 0; r_av[u] = 0;
-                const int d = ds[u];
-                if (d >= 0 && d != my && bit_of(alive, d)) {
-                    const bool mine = d >= c0 && d < c1;
-                    if (mine) {                                      // columns of this slice only: rx[d], ry[d] are its own
-                        dd[u] = d;
-                        r_dxi[u] = w1_ld8(dt[u] > tmx ? W + (int64_t)d * ld + mx : rx + d);
-                        r_dyi[u] = w1_ld8(dt[u] > tmy ? W + (int64_t)d * ld + my : ry + d);
-                    }
-                    if (a >= 0 && d != a && (mine || d == aprev)) {
-                        ad[u] = d; amine[u] = mine;
-                        r_av[u] = w1_ld8(dt[u] > ta ? W + (int64_t)d * ld + a : ra + d);
-                    }
-                }
-            }
+            unsigned long long r_h = 0, r_dp = 0;
+            if (lane == 62) r_h = w1_ld8(rx + my);                   // the merge height d(x, y)
+            if (lane == 63 && aprev >= 0) r_dp = w1_ld8(ra + aprev);
+            // d(a, x) and d(a, y): every replica works out d(a, y') itself and offers it to row a's scan AFTER the exchange
+            // (its index - y' - does not lie in the slice of the workgroup that owns column a)
+            unsigned long long r_ax = 0, r_ay = 0;
+            if (lane == 61 && a >= 0) { r_ax = w1_ld8(ra + mx); r_ay = w1_ld8(ra + my); }
             u32x4 qa[TRIPS], qb[TRIPS], qc[TRIPS];
 #pragma unroll
             for (int t = 0; t < TRIPS; t++) {
-                const int off = (c0 + 128 * t + 2 * lane) * 8;
+                const int off = (jl0 + 2 * t) * 8;
                 qa[t] = w1_ld16(bx, off);
                 qb[t] = w1_ld16(by, off);
                 qc[t] = u32x4{0u, 0u, 0u, 0u};
@@ -2071,9 +2075,7 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             }
             NN_FENCE();
             W1_STAMP(4);
-            NN_KEEP(r_nx); NN_KEEP(r_ny); NN_KEEP(r_h); NN_KEEP(r_dp);
-#pragma unroll
-            for (int u = 0; u < DCH; u++) { NN_KEEP(r_dxi[u]); NN_KEEP(r_dyi[u]); NN_KEEP(r_av[u]); }
+            NN_KEEP(r_nx); NN_KEEP(r_ny); NN_KEEP(r_h); NN_KEEP(r_dp); NN_KEEP(r_ax); NN_KEEP(r_ay);
 #pragma unroll
             for (int t = 0; t < TRIPS; t++) { NN_KEEP(qa[t]); NN_KEEP(qb[t]); NN_KEEP(qc[t]); }
             W1_STAMP(5);
@@ -2084,89 +2086,63 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             const double rcp = 1.0 / fs;
             ArgMinT rbest = {__builtin_inf(), 0x7fffffff, 0};   // this slice of the new row: the merged cluster's cache entry
             ArgMinT abest = {__builtin_inf(), 0x7fffffff, 0};   // this slice of row a: the streamed columns (ascending per lane)
-            ArgMinT acand = {__builtin_inf(), 0x7fffffff, 0};   // ... and its gathered candidates (dirty partners, the new cluster)
-            int ev = 0;                                         // a cached minimum of this slice was reached or undercut
+            bool ev = false;                                    // a cached minimum of this slice was reached or undercut
 #pragma unroll
             for (int t = 0; t < TRIPS; t++) {
-                const int j = c0 + 128 * t + 2 * lane;
-                if (j < c1) {
-                    const double2 xa = mw_pair(qa[t]);
-                    double2 b = mw_pair(qb[t]);
-                    const double2 va = mw_pair(qc[t]);
-                    const double2 nv = *reinterpret_cast<const double2*>(nnv + (j - c0));
-                    const uint2 ip = *reinterpret_cast<const uint2*>(nn + j);
-                    const uint32_t bits = smask[j >> 5] >> (j & 31);
-                    const bool w0 = (bits & 1u) && j != my, w1 = (bits & 2u) && j + 1 != my;
-                    if (w0) {
-                        b.x = div_by_small_int(fx * xa.x + fy * b.x, fs, rcp);
-                        if (b.x <= rbest.v) { if (b.x < rbest.v) { rbest.v = b.x; rbest.i = j; rbest.t = 0; } else rbest.t = 1; }
-                        if ((ip.x & 0xffffu) != NN_NOIDX && b.x <= nv.x) ev = 1;
-                        if (a >= 0) {
-                            if (j == a) acand = argmint_join(acand, b.x, my, 0);          // d(a, y'), computed a moment ago
-                            else if (va.x <= abest.v) { if (va.x < abest.v) { abest.v = va.x; abest.i = j; abest.t = 0; } else abest.t = 1; }
-                        }
-                    }
-                    if (w1) {
-                        b.y = div_by_small_int(fx * xa.y + fy * b.y, fs, rcp);
-                        if (b.y <= rbest.v) { if (b.y < rbest.v) { rbest.v = b.y; rbest.i = j + 1; rbest.t = 0; } else rbest.t = 1; }
-                        if ((ip.y & 0xffffu) != NN_NOIDX && b.y <= nv.y) ev = 1;
-                        if (a >= 0) {
-                            if (j + 1 == a) acand = argmint_join(acand, b.y, my, 0);
-                            else if (va.y <= abest.v) { if (va.y < abest.v) { abest.v = va.y; abest.i = j + 1; abest.t = 0; } else abest.t = 1; }
-                        }
-                    }
-                    // a pair store must not carry the OLD value of a dirty column (its own 8-byte store, below, is not ordered
-                    // against this one): elements that were not recomputed are left alone
-                    if (w0 && w1) {
-                        u32x4 pk;
-                        pk.x = (unsigned int)__double2loint(b.x); pk.y = (unsigned int)__double2hiint(b.x);
-                        pk.z = (unsigned int)__double2loint(b.y); pk.w = (unsigned int)__double2hiint(b.y);
-                        st16_sc1(ry + j, pk);
-                    }
-                    else if (w0) st8_sc1(ry + j, b.x);
-                    else if (w1) st8_sc1(ry + j + 1, b.y);
+                const int j = jl0 + 2 * t;
+                const bool in = j < c1;
+                const int jj = in ? j : c0;
+                const double2 xa = mw_pair(qa[t]);
+                const double2 bo = mw_pair(qb[t]);
+                double2 b;
+                const double2 va = mw_pair(qc[t]);
+                const double2 nv = *reinterpret_cast<const double2*>(nnv + (jj - c0));
+                const uint2 m2 = *reinterpret_cast<const uint2*>(meta + jj);
+                const bool w0 = in && (m2.x >> 24) != 255u && j != my, w1 = in && (m2.y >> 24) != 255u && j + 1 != my;
+                b.x = div_by_small_int(fx * xa.x + fy * bo.x, fs, rcp);
+                b.y = div_by_small_int(fx * xa.y + fy * bo.y, fs, rcp);
+                w1_upd(rbest, w0, b.x, j);
+                w1_upd(rbest, w1, b.y, j + 1);
+                ev = ev || (w0 && (m2.x & W1_NOIDX) != W1_NOIDX && b.x <= nv.x) || (w1 && (m2.y & W1_NOIDX) != W1_NOIDX && b.y <= nv.y);
+                if (a >= 0) {                                   // (uniform)
+                    w1_upd(abest, w0 && j != a, va.x, j);
+                    w1_upd(abest, w1 && j + 1 != a, va.y, j + 1);
                 }
-            }
-            // ---- the gathered values: dirty partners of the update, candidates of row a's scan
-            unsigned long long dpbits = r_dp; bool has_dp = lane == 63 && aprev_clean;
-#pragma unroll
-            for (int u = 0; u < DCH; u++) {
-                if (dd[u] >= 0) {
-                    const double dv = div_by_small_int(fx * nn_f64(r_dxi[u]) + fy * nn_f64(r_dyi[u]), fs, rcp);
-                    st8_sc1(ry + dd[u], dv);
-                    rbest = argmint_join(rbest, dv, dd[u], 0);
-                    if ((nn[dd[u]] & 0xffffu) != NN_NOIDX && dv <= nnv[dd[u] - c0]) ev = 1;
-                    if (dd[u] == a) acand = argmint_join(acand, dv, my, 0);      // d(a, y') for the scan of row a
-                }
-                if (ad[u] >= 0) {
-                    if (amine[u]) acand = argmint_join(acand, nn_f64(r_av[u]), ad[u], 0);
-                    if (ad[u] == aprev) { dpbits = r_av[u]; has_dp = true; }
+                // row y': the pair goes back as one 16-byte store - elements that were not recomputed (the diagonal, dead
+                // columns) carry the value just loaded; column y': the recomputed values at W[j][y'], one scattered 8-byte
+                // store per element (read later by the owner of column y' only; masked-out ones land in a dump slot)
+                {
+                    const double sx = w0 ? b.x : bo.x, sy = w1 ? b.y : bo.y;
+                    u32x4 pk;
+                    pk.x = (unsigned int)__double2loint(sx); pk.y = (unsigned int)__double2hiint(sx);
+                    pk.z = (unsigned int)__double2loint(sy); pk.w = (unsigned int)__double2hiint(sy);
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, by, j * 8, 0, 16);      // (sc1; lanes behind the slice are out of range: dropped)
+                    st8_sc1(w0 ? W + (int64_t)j * ld + my : dump, b.x);
+                    st8_sc1(w1 ? W + (int64_t)(j + 1) * ld + my : dump + 1, b.y);
                 }
             }
             W1_STAMP(6);
-            const unsigned long long dpb = __ballot(has_dp);
-            if (dpb) dprev = bcast_f64(dpbits, (int)__ffsll((long long)dpb) - 1);
-            if (acand.i != 0x7fffffff) abest = argmint_join(abest, acand.v, acand.i, acand.t);
-            rbest = argmint_wave_fast(rbest);
-            if (a >= 0) abest = argmint_wave_fast(abest);
-            ev = __any(ev) ? 1 : 0;
-            const double height = bcast_f64(r_h, 62);
+            if (aprev >= 0) dprev = bcast_f64(r_dp, 63);
+            rbest = argmint_wave_mono(rbest);
+            if (a >= 0) {
+                abest = argmint_wave_mono(abest);
+                ya = div_by_small_int(fx * bcast_f64(r_ax, 61) + fy * bcast_f64(r_ay, 61), fs, rcp);     // d(a, y'): the value the owner of column a stores
+            }
+            const int evu = __any(ev) ? 1 : 0;
+            const unsigned long long hb = (unsigned long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(r_h >> 32), 62) << 32) |
+                                                                (unsigned)__builtin_amdgcn_readlane((int)(r_h & 0xffffffffull), 62));
             if (wg == 0 && lane == 0) {
                 zraw[4 * (int64_t)step + 0] = (double)mx; zraw[4 * (int64_t)step + 1] = (double)my;
-                zraw[4 * (int64_t)step + 2] = height; zraw[4 * (int64_t)step + 3] = fs;
+                zraw[4 * (int64_t)step + 2] = __longlong_as_double((long long)hb); zraw[4 * (int64_t)step + 3] = fs;
             }
-            {
-                unsigned long long hb = (unsigned long long)__double_as_longlong(height);
-                if (inject_wrong > 0 && wg == 1 && step == inject_wrong) hb ^= 1ull;      // test hook: a replica that read a stale height
-                hash = (hash ^ hb) * 0x9E3779B97F4A7C15ull;
-                hash = (hash ^ (((unsigned long long)(unsigned)mx << 32) | (unsigned long long)(unsigned)my)) * 0xC2B2AE3D27D4EB4Full;
-                hash ^= (unsigned long long)(nx + ny) + (hash >> 29);
-            }
+            // this replica's record of the merge, folded into a running checksum (scalar: rotate, xor)
+            hash = ((hash << 7) | (hash >> 57)) ^ hb ^ (((unsigned long long)(unsigned)mx << 40) | ((unsigned long long)(unsigned)my << 16) | (unsigned long long)(unsigned)(nx + ny));
+            if (inject_wrong > 0 && wg == 1 && step == inject_wrong) hash ^= 1ull;    // test hook: a replica that read a stale height
             W1_STAMP(7);
             // every store of the pass is acknowledged before the mailbox store signals for them
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             W1_STAMP(8);
-            const int late = exchange(rbest, ev, abest, a >= 0, R, A, evm);
+            const int late = exchange(rbest, evu, abest, a >= 0, R, A, evm);
             if (late) stop_code = NN_STOP_LATE;
         }
         if (stop_code) break;
@@ -2174,35 +2150,29 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             for (int g = 0; g < S; g++) {
                 if (!((evm >> g) & 1ull)) continue;
                 const int g0 = g * slice < n ? g * slice : n, g1 = g0 + slice < n ? g0 + slice : n;
-                for (int i = g0 + lane; i < g1; i += 64) nn[i] = NN_NOIDX;
+                for (int i = g0 + lane; i < g1; i += 64) meta[i] |= W1_NOIDX;
             }
             __syncthreads();
         }
-        // ---- cluster y is dirty from now on and its neighbour is known; the fused scan of row a is decided like a scan on its own
+        // ---- the merged cluster's neighbour is known; the fused scan of row a is decided like a scan on its own
         tl++;
-#pragma unroll
-        for (int u = 0; u < DCH; u++) {
-            if (ds[u] == my) ds[u] = -1;                        // its older entry is superseded
-            if (u == ((tl - 1) >> 6) && lane == ((tl - 1) & 63)) { ds[u] = my; dt[u] = tl; }
-        }
         if (lane == 0) {
-            smask[my >> 5] &= ~(1u << (my & 31));
-            if (R.i >= 0 && R.i < n) {
-                nn[my] = w1_entry(R.i, R.t, tl);
-                if (my >= c0 && my < c1) nnv[my - c0] = R.v;
-            } else nn[my] = NN_NOIDX;
+            const bool known = R.i >= 0 && R.i < n;
+            meta[my] = (known ? (uint32_t)R.i | ((uint32_t)(R.t ? 1 : 0) << 15) : W1_NOIDX) | ((uint32_t)tl << 16) | ((uint32_t)tl << 24);
+            if (known && my >= c0 && my < c1) nnv[my - c0] = R.v;
         }
         if (a >= 0) {
-            if (A.i < 0 || A.i >= n) stop_code = NN_STOP_GUARD;
+            A = argmint_join(A, ya, my, 0);                         // the merged cluster itself is a candidate of row a's scan
+            if (A.i < 0 || A.i >= n) { stop_code = NN_STOP_GUARD; why = 5; }
             else {
                 int y = A.i;
                 if (aprev >= 0 && !(A.v < dprev)) y = aprev;
                 if (lane == 0) {
-                    nn[a] = w1_entry(y == aprev && aprev >= 0 ? aprev : A.i, A.t, tl);
+                    meta[a] = (uint32_t)(y == aprev && aprev >= 0 ? aprev : A.i) | ((uint32_t)(A.t ? 1 : 0) << 15) | ((uint32_t)tl << 16) | (ea & 0xff000000u);
                     if (a >= c0 && a < c1) nnv[a - c0] = A.v;
                 }
                 if (y != aprev) {
-                    if (++guard > 4 * n + 8) stop_code = NN_STOP_GUARD;
+                    if (++guard > 4 * n + 8) { stop_code = NN_STOP_GUARD; why = 6; }
                     push(y);
                 }
             }
@@ -2212,28 +2182,25 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
     }
     // ---- save the state for the flush / settle kernels and the next epoch
     __syncthreads();
+    unsigned long long npolls_max = 0;
+    if (PROF) { for (int l = 0; l < 64; l++) { const unsigned long long v = (unsigned long long)__builtin_amdgcn_readlane((int)npolls, l); if (v > npolls_max) npolls_max = v; } }
     for (int i = c0 + lane; i < c1; i += 64) w.nnval[i] = nnv[i - c0];      // every owner: its cached distances
     if (lane == 0) reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(w.mailw) + NN_W1_MAIL)[wg] = hash;
     if (wg != 0) return;
-    for (int i = lane; i < nwords; i += 64) w.alive[i] = alive[i];
-    for (int i = lane; i < n; i += 64) {
-        w.size[i] = (uint16_t)__hip_atomic_load(gsize + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        w.gtime[i] = -1;
-        w.nnc[i] = nn[i];                                       // with time stamps: k_nn_settle strips them
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < DCH; u++) {
-        const int k = u * 64 + lane;
-        if (k < tl) {
-            w.dslot[k] = ds[u]; w.dtime[k] = dt[u];
-            if (ds[u] >= 0) w.gtime[ds[u]] = dt[u];
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const uint32_t m = i < n ? meta[i] : 0xff000000u;
+        const unsigned long long al = __ballot((m >> 24) != 255u);
+        if (lane == 0) { w.alive[i0 >> 5] = (uint32_t)al; if (i0 + 32 < ((n + 31) & ~31)) w.alive[(i0 >> 5) + 1] = (uint32_t)(al >> 32); }
+        if (i < n) {
+            w.size[i] = (uint16_t)__hip_atomic_load(gsize + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w.gtime[i] = -1;                                    // (no deferred columns)
+            w.newidx[i] = (int)m;                               // with time stamps: k_nn_settle strips them (newidx: free between compactions)
         }
     }
     if (lane == 0) {
         w.state[0] = step; w.state[1] = len; w.state[2] = top; w.state[3] = second; w.state[4] = first_ptr;
-        w.state[5] = stop_code; w.state[6] = tl;
+        w.state[5] = stop_code; w.state[6] = 0; if (why) w.state[13] = why;
         w.prof[5] += c_cols; w.prof[6] += c_scans; w.prof[7] += c_hits;
         if (PROF) {
             w.prof[0] += tp[0]; w.prof[1] += tp[1]; w.prof[2] += tp[2]; w.prof[3] += tp[3];
@@ -2242,6 +2209,8 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             // stores acknowledged / -
             p2[0] += tp[4]; p2[2] += tp[5]; p2[3] += tp[6]; p2[4] += tp[7]; p2[5] += tp[8];
             w.prof[4] += tp[4] + tp[5] + tp[6] + tp[7] + tp[8];
+            w.prof[2] += tp[9];                                   // "pick" = post + polling + reductions + what follows the exchange
+            p2[8] += tp[9]; p2[9] += (unsigned long long)xseq; p2[10] += npolls_max;
         }
     }
 #undef W1_STAMP
@@ -2249,17 +2218,17 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
 
 // Between two epochs of k_nn_epoch_w1: cache entries that went stale during the epoch (their slot died, or merged after
 // the entry was written) become "unknown", the others lose their time stamp - the form k_nn_remap, k_nn_epoch_nc and the
-// next epoch expect.
+// next epoch expect (idx | tie << 16, 0xffff = unknown).
 __global__ __launch_bounds__(256) void k_nn_settle(NNWorkspace w, int n)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t e = w.nnc[i];
-    const uint32_t idx = e & 0xffffu;
+    const uint32_t e = (uint32_t)w.newidx[i];                  // the epoch's words: idx | tie << 15 | stamp << 16 | mtime << 24
+    const uint32_t idx = e & W1_NOIDX;
     uint32_t out = NN_NOIDX;
-    if (idx != NN_NOIDX && (int)idx < n && ((w.alive[idx >> 5] >> (idx & 31)) & 1u)) {
-        const int g = w.gtime[idx];
-        if (g < 0 || g <= (int)(e >> 17)) out = idx | (e & 0x10000u);
+    if (idx != W1_NOIDX && (int)idx < n) {
+        const uint32_t mt = (uint32_t)w.newidx[idx] >> 24;
+        if (mt != 255u && mt <= ((e >> 16) & 0xffu)) out = idx | (((e >> 15) & 1u) << 16);
     }
     w.nnc[i] = out;
 }
@@ -2504,8 +2473,8 @@ static bool w1_plan(int n, int cols, int max_s, int force_s, int* S_out, int* sl
     while (slice > 16 * 128 && S < NN_W1_MAXS) { S++; slice = (((n + S - 1) / S) + 63) & ~63; }
     if (slice > 16 * 128) return false;
     S = (n + slice - 1) / slice;                                  // (rounding the width up can leave the last slices empty)
-    const int nwords = (n + 31) / 32, nw4 = (nwords + 3) & ~3, n4 = (n + 3) & ~3;
-    const size_t lds = align16((size_t)nw4 * 8 + (size_t)n4 * 4 + (size_t)slice * 8);
+    const int n4 = (n + 3) & ~3;
+    const size_t lds = align16((size_t)n4 * 4 + (size_t)slice * 8);
     if (lds > w1_lds_room()) return false;
     *S_out = S; *slice_out = slice; *lds_out = lds;
     return true;
@@ -2554,9 +2523,9 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     const char* w1_maxs_text = getenv("HICMI_NNCHAIN_W1_MAXS");
     const bool w1_on = !(w1_text && atoi(w1_text) == 0) && !wgs_text && !force_single && !plain && !fused1 && !mw_old && !force_gsize;
     const int w1_force_s = w1_s_text ? atoi(w1_s_text) : 0;
-    const int w1_cols = w1_cols_text ? (atoi(w1_cols_text) > 64 ? atoi(w1_cols_text) : 64) : 512;
+    const int w1_cols = w1_cols_text ? (atoi(w1_cols_text) > 64 ? atoi(w1_cols_text) : 64) : 256;
     const int w1_max_s = w1_maxs_text ? atoi(w1_maxs_text) : NN_W1_MAXS;
-    if (w1_on && dcap > 64 * NN_W1_DCH) dcap = 64 * NN_W1_DCH;           // its dirty list: four entries per lane
+    if (w1_on && dcap > NN_W1_DCAP) dcap = NN_W1_DCAP;                   // its dirty list: four entries per lane, 8-bit times
     const int gsize_max = (n > NN_MWC_MAX || force_gsize) ? mwc_gsize_max_columns() : 0;
     if (dcap < 1) dcap = 1;
     if (dcap > NN_DMAX) dcap = NN_DMAX;
@@ -2597,6 +2566,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
         // cache alone in LDS - 64,000 columns fit; 8 or 16 slices
         const bool gsize = wgs_e >= 8 && (n_cur > NN_MWC_MAX || force_gsize) && n_cur <= gsize_max;
         int w1_S = 0, w1_slice = 0; size_t w1_lds = 0;
+        bool flush_needed = true;
         if (w1_on && w1_plan(n_cur, w1_cols, w1_max_s, w1_force_s, &w1_S, &w1_slice, &w1_lds)) {
             if (!cache_valid || (refresh_below > 0 && n_cur <= refresh_below)) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
             cache_valid = true;
@@ -2604,6 +2574,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
             launch_w1(profile, w1_S, w1_slice, w1_lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
             hipLaunchKernelGGL(k_nn_settle, dim3((n_cur + 255) / 256), dim3(256), 0, s, w, n_cur);
             hipLaunchKernelGGL(k_nn_check_hashes, dim3(1), dim3(64), 0, s, w, w1_S);
+            flush_needed = false;                                   // it keeps the matrix symmetric itself
         }
         else if (sliced && !plain && !mw_old && (n_cur <= NN_MWC_MAX || gsize)) {
             // column slices + neighbour cache + the next scan fused into the update (k_nn_epoch_mwc)
@@ -2646,7 +2617,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
         const int did = total_steps - done < dcap ? total_steps - done : dcap;
         done += did;
         if (done >= total_steps) break;
-        hipLaunchKernelGGL(k_nn_flush, dim3((n_cur + 255) / 256, dcap), dim3(256), 0, s, cur, ldw, n_cur, w);
+        if (flush_needed) hipLaunchKernelGGL(k_nn_flush, dim3((n_cur + 255) / 256, dcap), dim3(256), 0, s, cur, ldw, n_cur, w);
         const int live = n - done;
         if (compact && other && live >= 2 && (int64_t)live * 4 <= (int64_t)n_cur * 3) {
             hipLaunchKernelGGL(k_nn_translate, dim3((done - interval_start + 255) / 256), dim3(256), 0, s, zraw, interval_start,

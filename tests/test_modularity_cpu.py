@@ -1,8 +1,10 @@
-"""Louvain tail (scaffoldToChromosomes.py:239-349).  python-louvain / networkx are not installed
-and the reference never seeds its random state, so there is nothing to compare bit for bit: PARITY UNPINNED,
-checked statistically - planted groups are recovered, the modularity value equals the textbook definition
-evaluated edge by edge, the bookkeeping around the partition (group order, cut indices, head untouched)
-follows the reference's code, and a seed makes the run reproducible."""
+"""Louvain tail (scaffoldToChromosomes.py:239-349).  python-louvain (`community`) is not installed and the
+reference never seeds its random state, so there is nothing to compare bit for bit: PARITY UNPINNED against python-louvain,
+checked three ways - planted groups are recovered; the graph, its weights and the modularity value are compared with
+networkx (installed here: the reference's own `nx.Graph.add_edge` loop, `networkx.algorithms.community.modularity`); and the
+best-of-rounds score is compared with networkx's own Louvain (`louvain_communities(seed=s)`) over ten seeds.  The bookkeeping
+around the partition (group order, cut indices, head untouched) follows the reference's code, and a seed makes the run
+reproducible."""
 import numpy as np
 
 import golden_cases as gc
@@ -101,3 +103,84 @@ def test_part1_with_the_reference_default_modularity(tmp_path, monkeypatch):
     ids = [int(l.split("\t")[0]) for l in outs[0].splitlines() if not l.startswith("#")]
     assert len(ids) == len(set(ids)) and len(ids) > 0
     assert outs[0].count("### Chromosome group") >= 2
+
+
+# ---------------------------------------------------------------------------------- against networkx (installed here)
+def _reference_graph(adjacency, start):
+    """The reference's own graph construction (S2C:285-297) with real networkx: one node per tail bin, add_edge for EVERY
+    ordered pair (so the later call - the lower triangle - overwrites), self loops included."""
+    import networkx as nx
+    a = np.asarray(adjacency)
+    g = nx.Graph()
+    m = len(a) - start
+    for i in range(m):
+        g.add_node(i)
+    for i, r in enumerate(a[start:]):
+        for ii, v in enumerate(r[start:]):
+            g.add_edge(i, ii, weight=v)
+    return g
+
+
+def _tails():
+    """Three tails: the log-similarity tail of the n400_default fixture behind its last first-pass cut, and two synthetic
+    ones (planted groups, asymmetric noise so that "the later add_edge wins" matters)."""
+    import hic_oracle as orc
+    from hic_genome_assembler_amd import modularity as mod
+    spec, meta, gold, lay, c = gc.load_case("n400_default")
+    dist = orc.to_distance(c)
+    leaves, _z = orc.average_cluster_leaves(dist)
+    bins = [orc.Bin(i, "s", 0, 0, 0.0, 0.0) for i in range(len(c))]
+    _m, bins = orc.remove_zero_rows(c.copy(), bins)
+    sim = orc.to_similarity(dist[:, leaves][leaves], [bins[i] for i in leaves])
+    start = int(len(c) * 0.87)
+    out = [mod.log_transform(sim)[start:, start:]]
+    rng = np.random.default_rng(31)
+    for sizes in ([14, 9, 21, 6], [25, 25, 10]):
+        raw, _label = _planted(sizes, rng)
+        out.append(raw)
+    return out
+
+
+def test_graph_and_modularity_equal_networkx():
+    """modularity.graph_weights is the weight matrix of the graph the reference builds with nx.Graph.add_edge, and
+    modularity.modularity is networkx.algorithms.community.modularity on it (python-louvain's value: same definition)."""
+    import networkx as nx
+    from networkx.algorithms.community import modularity as nx_modularity
+    from hic_genome_assembler_amd import modularity as mod
+    for tail in _tails():
+        g = _reference_graph(tail, 0)
+        A = mod.graph_weights(tail)
+        W = nx.to_numpy_array(g, nodelist=list(range(len(tail))), weight="weight")
+        assert np.array_equal(W, A)                                         # incl. self loops on the diagonal
+        assert g.number_of_edges() == len(A) * (len(A) - 1) // 2 + len(A)   # the count the reference prints (S2C:300)
+        rng = np.random.default_rng(len(tail))
+        for k in (1, 2, 5, len(tail)):
+            part = rng.integers(0, k, len(tail)) if k < len(tail) else np.arange(len(tail))
+            comms = [set(np.flatnonzero(part == cidx).tolist()) for cidx in np.unique(part)]
+            q_nx = nx_modularity(g, comms, weight="weight")
+            assert abs(mod.modularity(part, A) - q_nx) < 1e-12
+
+
+def test_best_of_rounds_matches_networkx_louvain():
+    """The seeded restatement of python-louvain against networkx's independent Louvain implementation on the same graph:
+    over ten seeds the best-of-louvainRounds modularity agrees within 2 % (both are randomised local searches; neither
+    reproduces the unseeded reference run - parity stays unpinned vs python-louvain), and the restatement's partition
+    scores the same under networkx's modularity."""
+    from networkx.algorithms.community import louvain_communities, modularity as nx_modularity
+    from hic_genome_assembler_amd import modularity as mod
+    import contextlib
+    import io
+    for tail in _tails():
+        g = _reference_graph(tail, 0)
+        A = mod.graph_weights(tail)
+        ours, theirs = [], []
+        for seed in range(10):
+            with contextlib.redirect_stdout(io.StringIO()):
+                part, score = mod.modularity_rounds(A, louvain_rounds=4, seed=seed)
+            comms = [set(np.flatnonzero(part == cidx).tolist()) for cidx in np.unique(part)]
+            assert abs(score - nx_modularity(g, comms, weight="weight")) < 1e-12
+            ours.append(score)
+            theirs.append(max(nx_modularity(g, louvain_communities(g, weight="weight", seed=4 * seed + r), weight="weight")
+                              for r in range(4)))
+        assert abs(max(ours) - max(theirs)) <= 0.02 * abs(max(theirs)) + 1e-9
+        assert abs(np.mean(ours) - np.mean(theirs)) <= 0.02 * abs(np.mean(theirs)) + 1e-9
