@@ -30,7 +30,7 @@ static constexpr int NN_DMAX = 1024;                     // at most one dirty en
 static constexpr int NN_MAXWG = 16;                      // workgroups of the column-sliced chain (k_nn_epoch_mw / _mwc)
 static constexpr int NN_HEAD = 1536;                     // state 64 B, counters 64 B, hand-off slot 128 B, mailboxes 1024 B, profile detail 256 B
 static constexpr int NN_W1_MAXS = 64;                    // column slices (single-wave workgroups) of k_nn_epoch_w1
-static constexpr int NN_W1_MAIL = 2 * NN_W1_MAXS * 2 * 16;   // its mailboxes: 2 parities x 64 workgroups x 2 slots x 16 bytes
+static constexpr int NN_W1_MAIL = 2 * NN_W1_MAXS * 2 * NN_W1_MAXS * 16;   // its mailboxes: 2 parities x 64 readers x (2 slots x 64 writers) x 16 bytes
 
 struct ArgMin { double v; int i; };
 
@@ -1806,19 +1806,53 @@ __device__ __forceinline__ void w1_upd(ArgMinT& b, bool live, double v, int j)
     b.v = lt ? v : b.v;
 }
 
+// Wave minimum of an fp64 value, in every lane: four DPP exchanges inside the rows of 16 lanes, then gfx950's
+// v_permlane16_swap / v_permlane32_swap across the rows (min of both halves of a swap needs no select).  v_min_f64 comes from
+// inline assembly: fmin() under IEEE rules costs a canonicalising v_max_f64 per operand - on ONE wave, where every
+// instruction is ~4 cycles of the merge's critical path, a reduction of ~55 instructions becomes ~20.
+__device__ __forceinline__ double w1_vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <int CTRL>
+__device__ __forceinline__ double w1_min_dpp(double v)
+{
+    const int olo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);      // (every lane has a source: no copy of v first)
+    const int ohi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return w1_vmin(v, __hiloint2double(ohi, olo));
+}
+__device__ __forceinline__ double w1_wave_min(double v)
+{
+    v = w1_min_dpp<0xB1>(v); v = w1_min_dpp<0x4E>(v); v = w1_min_dpp<0x141>(v); v = w1_min_dpp<0x140>(v);
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = w1_vmin(__hiloint2double((int)h[0], (int)l[0]), __hiloint2double((int)h[1], (int)l[1]));
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = w1_vmin(__hiloint2double((int)h[0], (int)l[0]), __hiloint2double((int)h[1], (int)l[1]));
+    }
+    return v;
+}
 // Wave arg-min when the candidates' indices do not decrease with the lane (a lane owns a contiguous run of columns;
 // a peer owns a contiguous slice): the lowest index at the minimum is the lowest LANE at the minimum - one ballot instead
-// of a second DPP reduction.  Result uniform; i = 0x7fffffff when nothing compares (no candidates / NaN).
-__device__ __forceinline__ ArgMinT argmint_wave_mono(ArgMinT a)
+// of a second reduction.  `odd` >= 0: candidates may also carry that one index out of order (row a's scan is offered
+// d(a, y') by whoever owns column a; y' need not lie in its slice) - it wins an exact tie iff it is the lower index.
+// Result uniform; i = 0x7fffffff when nothing compares (no candidates / NaN).
+__device__ __forceinline__ ArgMinT argmint_wave_mono(ArgMinT a, int odd = -1)
 {
-    double m = a.v;
-    m = fmin_dpp_step<0xB1>(m); m = fmin_dpp_step<0x4E>(m); m = fmin_dpp_step<0x141>(m); m = fmin_dpp_step<0x140>(m);
-    const double mv = fmin(fmin(readlane_f64(m, 0), readlane_f64(m, 16)), fmin(readlane_f64(m, 32), readlane_f64(m, 48)));
-    const unsigned long long at = __ballot(a.v == mv && a.i != 0x7fffffff);
-    ArgMinT r = {mv, 0x7fffffff, 0};
+    const double m = w1_wave_min(a.v);
+    const unsigned long long at = __ballot(a.v == m && a.i != 0x7fffffff);
+    ArgMinT r;
+    r.v = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(m)), __builtin_amdgcn_readfirstlane(__double2loint(m)));
+    r.i = 0x7fffffff; r.t = 0;
     if (at) {
-        const int l = (int)__ffsll((long long)at) - 1;
+        const unsigned long long at_odd = odd >= 0 ? (at & __ballot(a.i == odd)) : 0ull;
+        const unsigned long long at_ord = at & ~at_odd;
+        int l = at_ord ? (int)__ffsll((long long)at_ord) - 1 : (int)__ffsll((long long)at_odd) - 1;
         r.i = __builtin_amdgcn_readlane(a.i, l);
+        if (at_odd && odd < r.i) { r.i = odd; l = (int)__ffsll((long long)at_odd) - 1; }
         r.t = ((at & (at - 1ull)) != 0ull || __builtin_amdgcn_readlane(a.t, l) != 0) ? 1 : 0;
     }
     return r;
@@ -1884,7 +1918,8 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
 
     int tl = 0;                                              // merges of this epoch so far: the local clock
     int lowmark = len;                                       // chain entries below this are still the earlier epochs'
-    unsigned int xseq = 0u;
+    unsigned int xseq = (unsigned int)w1_uni(w.state[14]);   // exchanges so far in this map: the mailboxes are cleared once per map
+    const unsigned int xseq0 = xseq;
     int guard = 0, stop_code = 0, why = 0;                   // why: which check stopped the chain (diagnostics, state[13])
     unsigned long long hash = 0x243F6A8885A308D3ull;         // of this replica's merge records
     unsigned long long c_cols = 0, c_scans = 0, c_hits = 0;
@@ -1909,11 +1944,18 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
         return w1_uni(__hip_atomic_load((i < lowmark ? chain0 : chain) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     };
     // one exchange: slot 0 = (m0, event flag), slot 1 = m1 (when `two`); results uniform.  Returns 1 when a peer was late.
-    auto exchange = [&](ArgMinT m0, int ev0, ArgMinT m1, bool two, ArgMinT& r0, ArgMinT& r1, unsigned long long& evm) -> int {
+    auto exchange = [&](ArgMinT m0, int ev0, ArgMinT m1, bool two, int odd1, ArgMinT& r0, ArgMinT& r1, unsigned long long& evm) -> int {
         xseq++;
-        u32x4* slots = mailw + (xseq & 1u) * (NN_W1_MAXS * 2);       // [slot 0 of every workgroup][slot 1 of every workgroup]
-        if (lane == 0) st16_sc1(slots + wg, w1_mail(m0.v, m0.i, m0.t, ev0, xseq));
-        if (two && lane == 1) st16_sc1(slots + NN_W1_MAXS + wg, w1_mail(m1.v, m1.i, m1.t, 0, xseq));
+        // Every reader has an INBOX of its own per parity - [slot 0 of every writer][slot 1 of every writer] - and every writer
+        // pushes its slots into all of them (lane p: reader p's inbox).  Polling then touches lines nobody else reads: with
+        // 64 readers spinning on the same 16 lines an exchange round took 1.4 us, with private inboxes 1.0 us (0.7 at 16).
+        u32x4* box = mailw + (size_t)(xseq & 1u) * (NN_W1_MAXS * 2 * NN_W1_MAXS);
+        if (lane < S && lane != wg) {
+            u32x4* theirs = box + (size_t)lane * (2 * NN_W1_MAXS) + wg;
+            st16_sc1(theirs, w1_mail(m0.v, m0.i, m0.t, ev0, xseq));
+            if (two) st16_sc1(theirs + NN_W1_MAXS, w1_mail(m1.v, m1.i, m1.t, 0, xseq));
+        }
+        const u32x4* slots = box + (size_t)wg * (2 * NN_W1_MAXS);
         ArgMinT o0 = {__builtin_inf(), 0x7fffffff, 0}, o1 = {__builtin_inf(), 0x7fffffff, 0};
         int late = 0, evbit = 0;
         if (lane < S) {
@@ -1936,10 +1978,11 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             }
         }
         if (inject_late > 0 && (int)xseq == inject_late) late = 1;       // test hook: a peer that never answers
+        (void)xseq0;
         W1_STAMP(9);                                                     // (PROF: post + polling, until every peer has answered)
         evm = __ballot(evbit != 0);
         r0 = argmint_wave_mono(o0);                                      // a peer's columns lie below the next peer's
-        if (two) r1 = argmint_wave_mono(o1);
+        if (two) r1 = argmint_wave_mono(o1, odd1);                       // (slot 1 may carry y', an index outside its sender's slice)
         return __any(late) ? 1 : 0;
     };
 
@@ -2006,7 +2049,7 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             W1_STAMP(1);
             ArgMinT m, m_unused = {__builtin_inf(), 0x7fffffff, 0};
             unsigned long long evm_unused;
-            const int late = exchange(best, 0, m_unused, false, m, m_unused, evm_unused);
+            const int late = exchange(best, 0, m_unused, false, -1, m, m_unused, evm_unused);
             if (late) stop_code = NN_STOP_LATE;
             else if (m.i < 0 || m.i >= n) { stop_code = NN_STOP_GUARD; why = 3; }
             else {
@@ -2048,7 +2091,7 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
         W1_STAMP(3);
         ArgMinT R = {__builtin_inf(), 0x7fffffff, 0}, A = {__builtin_inf(), 0x7fffffff, 0};
         unsigned long long evm = 0ull;
-        double dprev = __builtin_inf(), fs = 0.0, ya = __builtin_inf();
+        double dprev = __builtin_inf(), fs = 0.0;
         {
             const double* __restrict__ rx = W + (int64_t)mx * ld;
             double* __restrict__ ry = W + (int64_t)my * ld;
@@ -2060,10 +2103,6 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             unsigned long long r_h = 0, r_dp = 0;
             if (lane == 62) r_h = w1_ld8(rx + my);                   // the merge height d(x, y)
             if (lane == 63 && aprev >= 0) r_dp = w1_ld8(ra + aprev);
-            // d(a, x) and d(a, y): every replica works out d(a, y') itself and offers it to row a's scan AFTER the exchange
-            // (its index - y' - does not lie in the slice of the workgroup that owns column a)
-            unsigned long long r_ax = 0, r_ay = 0;
-            if (lane == 61 && a >= 0) { r_ax = w1_ld8(ra + mx); r_ay = w1_ld8(ra + my); }
             u32x4 qa[TRIPS], qb[TRIPS], qc[TRIPS];
 #pragma unroll
             for (int t = 0; t < TRIPS; t++) {
@@ -2075,7 +2114,7 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             }
             NN_FENCE();
             W1_STAMP(4);
-            NN_KEEP(r_nx); NN_KEEP(r_ny); NN_KEEP(r_h); NN_KEEP(r_dp); NN_KEEP(r_ax); NN_KEEP(r_ay);
+            NN_KEEP(r_nx); NN_KEEP(r_ny); NN_KEEP(r_h); NN_KEEP(r_dp);
 #pragma unroll
             for (int t = 0; t < TRIPS; t++) { NN_KEEP(qa[t]); NN_KEEP(qb[t]); NN_KEEP(qc[t]); }
             W1_STAMP(5);
@@ -2087,6 +2126,7 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             ArgMinT rbest = {__builtin_inf(), 0x7fffffff, 0};   // this slice of the new row: the merged cluster's cache entry
             ArgMinT abest = {__builtin_inf(), 0x7fffffff, 0};   // this slice of row a: the streamed columns (ascending per lane)
             bool ev = false;                                    // a cached minimum of this slice was reached or undercut
+            double ya = 0.0; bool has_ya = false;               // d(a, y'): the element of the new row at column a (its owner only)
 #pragma unroll
             for (int t = 0; t < TRIPS; t++) {
                 const int j = jl0 + 2 * t;
@@ -2105,8 +2145,11 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
                 w1_upd(rbest, w1, b.y, j + 1);
                 ev = ev || (w0 && (m2.x & W1_NOIDX) != W1_NOIDX && b.x <= nv.x) || (w1 && (m2.y & W1_NOIDX) != W1_NOIDX && b.y <= nv.y);
                 if (a >= 0) {                                   // (uniform)
-                    w1_upd(abest, w0 && j != a, va.x, j);
-                    w1_upd(abest, w1 && j + 1 != a, va.y, j + 1);
+                    const bool is0 = j == a, is1 = j + 1 == a;
+                    if (w0 && is0) { ya = b.x; has_ya = true; }
+                    if (w1 && is1) { ya = b.y; has_ya = true; }
+                    w1_upd(abest, w0 && !is0, va.x, j);
+                    w1_upd(abest, w1 && !is1, va.y, j + 1);
                 }
                 // row y': the pair goes back as one 16-byte store - elements that were not recomputed (the diagonal, dead
                 // columns) carry the value just loaded; column y': the recomputed values at W[j][y'], one scattered 8-byte
@@ -2125,8 +2168,12 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             if (aprev >= 0) dprev = bcast_f64(r_dp, 63);
             rbest = argmint_wave_mono(rbest);
             if (a >= 0) {
+                // the merged cluster itself is a candidate of row a's scan, offered by the owner of column a: its index - y' -
+                // need not lie in that workgroup's slice, so the reduction over the peers is the full lexicographic one
+                // (nobody else can work d(a, y') out: both copies of d(a, y) are being overwritten in this very pass)
                 abest = argmint_wave_mono(abest);
-                ya = div_by_small_int(fx * bcast_f64(r_ax, 61) + fy * bcast_f64(r_ay, 61), fs, rcp);     // d(a, y'): the value the owner of column a stores
+                const unsigned long long yb = __ballot(has_ya);
+                if (yb) abest = argmint_join(abest, bcast_f64((unsigned long long)__double_as_longlong(ya), (int)__ffsll((long long)yb) - 1), my, 0);
             }
             const int evu = __any(ev) ? 1 : 0;
             const unsigned long long hb = (unsigned long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(r_h >> 32), 62) << 32) |
@@ -2142,7 +2189,7 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             // every store of the pass is acknowledged before the mailbox store signals for them
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             W1_STAMP(8);
-            const int late = exchange(rbest, evu, abest, a >= 0, R, A, evm);
+            const int late = exchange(rbest, evu, abest, a >= 0, my, R, A, evm);
             if (late) stop_code = NN_STOP_LATE;
         }
         if (stop_code) break;
@@ -2162,7 +2209,6 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             if (known && my >= c0 && my < c1) nnv[my - c0] = R.v;
         }
         if (a >= 0) {
-            A = argmint_join(A, ya, my, 0);                         // the merged cluster itself is a candidate of row a's scan
             if (A.i < 0 || A.i >= n) { stop_code = NN_STOP_GUARD; why = 5; }
             else {
                 int y = A.i;
@@ -2201,6 +2247,7 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
     if (lane == 0) {
         w.state[0] = step; w.state[1] = len; w.state[2] = top; w.state[3] = second; w.state[4] = first_ptr;
         w.state[5] = stop_code; w.state[6] = 0; if (why) w.state[13] = why;
+        w.state[14] = (int)xseq;
         w.prof[5] += c_cols; w.prof[6] += c_scans; w.prof[7] += c_hits;
         if (PROF) {
             w.prof[0] += tp[0]; w.prof[1] += tp[1]; w.prof[2] += tp[2]; w.prof[3] += tp[3];
@@ -2210,7 +2257,7 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             p2[0] += tp[4]; p2[2] += tp[5]; p2[3] += tp[6]; p2[4] += tp[7]; p2[5] += tp[8];
             w.prof[4] += tp[4] + tp[5] + tp[6] + tp[7] + tp[8];
             w.prof[2] += tp[9];                                   // "pick" = post + polling + reductions + what follows the exchange
-            p2[8] += tp[9]; p2[9] += (unsigned long long)xseq; p2[10] += npolls_max;
+            p2[8] += tp[9]; p2[9] += (unsigned long long)(xseq - xseq0); p2[10] += npolls_max;
         }
     }
 #undef W1_STAMP
@@ -2530,6 +2577,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     if (dcap < 1) dcap = 1;
     if (dcap > NN_DMAX) dcap = NN_DMAX;
     hipLaunchKernelGGL(k_nn_init, dim3(64), dim3(256), 0, s, w, n);
+    if (w1_on) hipMemsetAsync(w.mailw, 0, NN_W1_MAIL, s);          // (its exchange numbers run on over the epochs of a map)
     if (profile) { static const int one = 1; hipMemcpyAsync(w.state + 8, &one, sizeof(int), hipMemcpyHostToDevice, s); }
     {
         static int hooks[2];                                     // test hooks: see NNWorkspace::state[10], [11]
@@ -2570,7 +2618,6 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
         if (w1_on && w1_plan(n_cur, w1_cols, w1_max_s, w1_force_s, &w1_S, &w1_slice, &w1_lds)) {
             if (!cache_valid || (refresh_below > 0 && n_cur <= refresh_below)) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
             cache_valid = true;
-            hipMemsetAsync(w.mailw, 0, NN_W1_MAIL, s);
             launch_w1(profile, w1_S, w1_slice, w1_lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
             hipLaunchKernelGGL(k_nn_settle, dim3((n_cur + 255) / 256), dim3(256), 0, s, w, n_cur);
             hipLaunchKernelGGL(k_nn_check_hashes, dim3(1), dim3(64), 0, s, w, w1_S);
