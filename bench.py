@@ -14,6 +14,12 @@ Rank 0 prints ONE JSON line (contract in the task prompt) with these extra objec
   roofline_all   - the same figure for every Part 1 kernel family (one extra, untimed step with events around every
                    launch), so the HBM-bound kernels are visible next to the latency-bound chain;
   north_star_32k - the same step on a 32,000-bin map (north_star's single-GPU target size), a few steps;
+  configs4_64k_f32 - the same step on BASELINE configs[4]'s map (64,000 bins, fp32-valued contacts) on this one GPU;
+  mfma           - the matrix-core contraction of Part 2 (k_win_outside_mfma, v_mfma_f64_16x16x4_f64): flops counted by
+                   the library / its device time from this run, instruction counters from the latest committed
+                   rocprofv3 --pmc collection, against the 78.6 TF FP64-matrix peak;
+  e2e            - the drop-in CLI from files to files: 2,000 bins from HiC-Pro text, 16,000 bins from the binary matrix
+                   cache (HICMI_MATRIX_CACHE, warm .npy);
   cpu_baseline   - the CPU oracle (a port of the reference's NumPy/SciPy path, oracle/) timed on this box's host
                    cores on BASELINE configs[0] (2,000 bins), with and without the reference's unused
                    frozen-distribution construction (scaffoldToChromosomes.py:364).
@@ -151,41 +157,126 @@ def e2e_cli(n_bins, work):
             "what": "run_hicAssembler.py -part1 -part2 -config: HiC-Pro text -> six files, plots off, matrix parsed once"}
 
 
-def pmc_traffic(n, fam):
+def e2e_cli_cached(n_bins, work, dev):
+    """The same CLI at 16,000 bins with the matrix read from its binary cache (HICMI_MATRIX_CACHE: hostio.py writes a .npy
+    copy beside the HiC-Pro text the first time it parses it; S2C:70-98 / OG:30-93 replaced).  Writing the 128 M-line text of a
+    16k map takes minutes, so the cache is filled directly here: a one-line placeholder .matrix whose size / mtime the cache
+    key names, the synthetic map as the .npy.  Timed: warm .npy (memory-mapped) -> upload -> both parts -> six files."""
+    import numpy as np
+    from hic_genome_assembler_amd import hostio, run_hicAssembler, synth
+    lay = synth.make_layout(n_bins, seed=1)
+    c = synth.dense_contacts_torch(lay, dev, seed=1, sinkhorn_iters=12).cpu().numpy()
+    paths = synth.write_hicpro(os.path.join(work, "in"), lay, None, "e2e16k")
+    npy, key_file = hostio._cache_paths(paths["hicProMatrixFile"], "1")
+    np.save(npy, c, allow_pickle=False)
+    with open(key_file, "w") as fh:
+        json.dump(hostio._cache_key(paths["hicProMatrixFile"], lay.bin_ids), fh)
+    del c
+    cfg = synth.write_config(os.path.join(work, "config.txt"), paths, os.path.join(work, "out"), os.path.join(work, "plots"),
+                             lay.resolution, min_size=5, modularity=0.0, psig=0.05, n_scaffolds=6, scan_scaffolds=5)
+    os.environ["HICMI_NO_PLOTS"] = "1"
+    os.environ["HICMI_MATRIX_CACHE"] = "1"
+    times = []
+    try:
+        for _ in range(2):
+            t0 = time.time()
+            run_hicAssembler.main(["-part1", "-part2", "-c", cfg])
+            times.append(time.time() - t0)
+    finally:
+        del os.environ["HICMI_MATRIX_CACHE"]
+    return {"bins": n_bins, "seconds_first_run": round(times[0], 3), "seconds_second_run": round(times[1], 3),
+            "matrix_cache_MB": round(os.path.getsize(npy) / 1e6, 1),
+            "what": "run_hicAssembler.py -part1 -part2 -config with HICMI_MATRIX_CACHE=1: warm .npy (no text parse) -> six files, "
+                    "plots off; the text parse of such a map (128 M triplets) is 3.4 s once (DESIGN.md 8b)"}
+
+
+def pmc_traffic(n, fam, launches_per_step):
     """HBM bytes per launch of a kernel family from the latest committed rocprofv3 --pmc collection for this map size
-    (profiles/r*_pmc_part1_<n/1000>k.json; 2 x FETCH_SIZE + WRITE_SIZE: MI355X_MICROARCH.md, FETCH_SIZE counts half
-    of a wide coalesced read stream on gfx950).  PMC collection cannot run inside the timed process."""
+    (profiles/r*_pmc_part1_<n/1000>k.json, ONE Part 1 pass; 2 x FETCH_SIZE + WRITE_SIZE: MI355X_MICROARCH.md, FETCH_SIZE
+    counts half of a wide coalesced read stream on gfx950), summed over every kernel of the family and divided by the
+    family's launches per step.  PMC collection cannot run inside the timed process, so the figure goes stale when a
+    kernel changes after the collection: the source string names the file and the commit it was collected at."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_part1_%dk.json" % (n // 1000))))
-    if not files or fam not in PMC_KERNELS:
+    if not files or fam not in PMC_KERNELS or launches_per_step <= 0:
         return None, None
     with open(files[-1]) as fh:
         pmc = json.load(fh)
     fetch = write = 0.0
-    dispatches = 0
+    seen = False
     for name, d in pmc.get("FETCH_SIZE", {}).items():
         if name.startswith(PMC_KERNELS[fam]):
             fetch += d["sum_KB"]
-            dispatches += d["dispatches"]
+            seen = True
     for name, d in pmc.get("WRITE_SIZE", {}).items():
         if name.startswith(PMC_KERNELS[fam]):
             write += d["sum_KB"]
-    if not dispatches:
+    if not seen:
         return None, None
-    return ((2.0 * fetch + write) * 1024.0 / dispatches,
-            "profiles/%s (rocprofv3 --pmc passes, 2*FETCH_SIZE + WRITE_SIZE per dispatch)" % os.path.basename(files[-1]))
+    commit = pmc.get("_meta", {}).get("commit", "not recorded")
+    return ((2.0 * fetch + write) * 1024.0 / launches_per_step,
+            "profiles/%s (rocprofv3 --pmc passes over one Part 1 pass, 2*FETCH_SIZE + WRITE_SIZE summed over the family's "
+            "kernels / its launches per step; collected at commit %s)" % (os.path.basename(files[-1]), commit))
 
 
-def family_table(timing, steps, n):
+FP64_MATRIX_PEAK_TFLOPS = 78.6      # MI355X_MICROARCH.md / SURVEY 8d: FP64 vector = FP64 matrix
+
+
+def family_table(timing, steps, n, workers):
+    """Every kernel family with its algorithmic bytes per launch against the HBM peak.  Part 2 families run on
+    `workers` concurrent streams (and the lock-step insertion as one region per chromosome group): their `ms_per_step` is
+    device time SUMMED over the streams, their share of the wall clock about 1/workers of it."""
     out = {}
     for k, v in timing.items():
-        if v["launches"] == 0 or v["ms"] <= 0 or v["bytes"] <= 0 or k.startswith("p2_") or k == "plot":
+        if v["launches"] == 0 or v["ms"] <= 0 or v["bytes"] <= 0 or k == "plot" or k.endswith("_flops"):
             continue
         avg_ms = v["ms"] / v["launches"]
         gbs = v["bytes"] / v["launches"] / (avg_ms * 1e-3) / 1e9
-        traffic, _src = pmc_traffic(n, k)
-        out[k] = {"ms_per_step": round(v["ms"] / steps, 3), "launches_per_step": v["launches"] / steps,
+        lps = v["launches"] / steps
+        traffic, _src = pmc_traffic(n, k, lps)
+        out[k] = {"ms_per_step": round(v["ms"] / steps, 3), "launches_per_step": lps,
                   "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": v["bytes"] / v["launches"],
                   "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic}
+        if k.startswith("p2_"):
+            out[k]["summed_over_streams"] = workers
+    fl = timing.get("p2_window_G_flops")
+    if fl and fl["bytes"] > 0 and "p2_window_G" in out and timing["p2_window_G"]["ms"] > 0:
+        tf = fl["bytes"] / (timing["p2_window_G"]["ms"] * 1e-3) / 1e12
+        out["p2_window_G"].update({"bound": "mfma (the outside table is a GEMM on v_mfma_f64_16x16x4_f64; the family's time also "
+                                            "holds the pair tables and the candidate look-ups)",
+                                   "gemm_flops_per_step": fl["bytes"] / steps, "achieved_TFLOPs": round(tf, 2),
+                                   "frac_fp64_matrix_peak": round(tf / FP64_MATRIX_PEAK_TFLOPS, 4)})
+    return out
+
+
+def mfma_object(timing, steps):
+    """north_star: "MFMA-utilisation counters reported against chip peak".  The only matrix-core kernel of the path is Part
+    2's k_win_outside_mfma (the reference has no row x row^T contraction; the results-neutral GEMM is
+    the window tables' outside term).  Flops: counted by the library (2 m^2 (n - m) per window); time: the window-table
+    family of this run (all its kernels, summed over the worker streams); instruction counters: the latest committed
+    rocprofv3 --pmc collection (they cannot be read inside the timed process)."""
+    out = {"kernel": "hicmi::k_win_outside_mfma", "instruction": "v_mfma_f64_16x16x4_f64", "peak_TFLOPs": FP64_MATRIX_PEAK_TFLOPS}
+    fl, fam = timing.get("p2_window_G_flops"), timing.get("p2_window_G")
+    if fl and fam and fam["ms"] > 0:
+        tf = fl["bytes"] / (fam["ms"] * 1e-3) / 1e12
+        out.update({"gemm_flops_per_step": fl["bytes"] / steps, "window_table_family_ms_per_step": round(fam["ms"] / steps, 3),
+                    "achieved_TFLOPs_over_the_family": round(tf, 2), "frac_of_peak_over_the_family": round(tf / FP64_MATRIX_PEAK_TFLOPS, 4)})
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma_16k.json")))
+    if files:
+        with open(files[-1]) as fh:
+            pmc = json.load(fh)
+
+        def total(counter):
+            return sum(d["sum"] for name, d in pmc.get(counter, {}).items() if name.startswith("hicmi::k_win_outside_mfma"))
+        inst, mops, busy, sq = (total(c) for c in ("SQ_INSTS_VALU_MFMA_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64",
+                                                   "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES"))
+        ksec = pmc.get("_meta", {}).get("k_win_outside_mfma_ms_per_step")
+        out["counters"] = {"source": "profiles/%s (one 16,000-bin step; collected at commit %s)"
+                                     % (os.path.basename(files[-1]), pmc.get("_meta", {}).get("commit", "not recorded")),
+                           "SQ_INSTS_VALU_MFMA_F64": inst, "GFLOP_per_step": mops * 512.0 / 1e9,
+                           "SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_BUSY_CYCLES_of_the_kernel": sq,
+                           "kernel_ms_per_step_in_that_collection": ksec,
+                           "frac_of_peak_of_the_kernel_alone": (round(mops * 512.0 / 1e12 / (ksec * 1e-3) / FP64_MATRIX_PEAK_TFLOPS, 4)
+                                                                if ksec else None)}
     return out
 
 
@@ -275,7 +366,7 @@ def roofline_of(timing, stats, steps, n, workers):
     avg_ms = d["ms"] / max(d["launches"], 1)
     bytes_per_launch = d["bytes"] / max(d["launches"], 1)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(n, fam)
+    traffic, traffic_src = pmc_traffic(n, fam, d["launches"] / max(steps, 1))
     out = {"bound": "hbm", "kernel": fam, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
            "avg_launch_ms": avg_ms, "launches_per_step": d["launches"] / max(steps, 1),
@@ -305,6 +396,7 @@ def main():
     ap.add_argument("--cpu-sample-bins", type=int, default=2000, help="BASELINE configs[0]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-32k", action="store_true", help="skip the north_star_32k object")
+    ap.add_argument("--no-64k", action="store_true", help="skip the configs4_64k_f32 object")
     ap.add_argument("--no-table", action="store_true", help="skip the extra untimed step behind roofline_all")
     ap.add_argument("--no-e2e", action="store_true", help="skip the text-to-files run of the CLI at 2,000 bins")
     ap.add_argument("--weak", action="store_true",
@@ -357,7 +449,8 @@ def main():
                       else "Part1 wall-clock (s) and bins/s on N x N contact map",
             "value": value, "unit": "bins/s", "n_gpus": world if args.backend == "nccl" else min(world, n_devices),
             "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if one_map else "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": ("strong" if one_map else "weak") if world > 1 else None,
             "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload_label(n, args.part1_only, args.f32),
@@ -381,25 +474,35 @@ def main():
     if world == 1 and not args.no_table:
         # one more step, untimed, with events around EVERY launch: the per-kernel roofline table
         _e, t_all, _s = timed_run(job, 1, 0, 1, dist.barrier, reduce_dev)
-        out["roofline_all"] = family_table(t_all, 1, n)
+        out["roofline_all"] = family_table(t_all, 1, n, max(1, min(p2.WORKERS, 8)))
+        if not args.part1_only:
+            out["mfma"] = mfma_object(t_all, 1)
     job.close()
     del job
     torch.cuda.empty_cache()
+    def side_job(bins, f32, k_steps, seed):
+        """The same step on another BASELINE size: its own synthetic map, one warm-up step, k_steps timed steps."""
+        j = Job(args, bins, dev, local, seed, None, f32=f32)
+        e, t, st = timed_run(j, k_steps, 1, timing_mode, dist.barrier, reduce_dev)
+        ms = e / k_steps * 1e3
+        obj = {"workload": workload_label(bins, False, f32), "value": bins / (ms / 1e3), "unit": "bins/s",
+               "ms_per_step": ms, "steps": k_steps, "warmup": 1, "cuts_found": len(j.last.get("cuts", [])),
+               "part1_s_per_step": round(j.parts[0] / max(j.parts[2], 1), 4),
+               "part2_s_per_step": round(j.parts[1] / max(j.parts[2], 1), 4),
+               "roofline": roofline_of(t, st, k_steps, bins, max(1, min(p2.WORKERS, 8))),
+               "kernels_ms_per_step": {k: round(v["ms"] / k_steps, 3) for k, v in t.items() if v["ms"] > 0}}
+        j.close()
+        del j
+        torch.cuda.empty_cache()
+        return obj
+
     if world == 1 and not args.no_32k and n != 32000 and not args.part1_only:
         # north_star's single-GPU target size, same step, a few repetitions (its own synthetic map)
-        job32 = Job(args, 32000, dev, local, 1, None)
-        k32 = 3
-        e32, t32, s32 = timed_run(job32, k32, 1, timing_mode, dist.barrier, reduce_dev)
-        ms32 = e32 / k32 * 1e3
-        out["north_star_32k"] = {"workload": workload_label(32000, False), "value": 32000 / (ms32 / 1e3), "unit": "bins/s",
-                                 "ms_per_step": ms32, "steps": k32, "warmup": 1, "cuts_found": len(job32.last.get("cuts", [])),
-                                 "part1_s_per_step": round(job32.parts[0] / max(job32.parts[2], 1), 4),
-                                 "part2_s_per_step": round(job32.parts[1] / max(job32.parts[2], 1), 4),
-                                 "roofline": roofline_of(t32, s32, k32, 32000, max(1, min(p2.WORKERS, 8))),
-                                 "kernels_ms_per_step": {k: round(v["ms"] / k32, 3) for k, v in t32.items() if v["ms"] > 0}}
-        job32.close()
-        del job32
-        torch.cuda.empty_cache()
+        out["north_star_32k"] = side_job(32000, False, 3, 1)
+    if world == 1 and not args.no_64k and n != 64000 and not args.part1_only:
+        # BASELINE configs[4]'s map on ONE GPU: 64,000 bins, contacts rounded to fp32 values (every row then holds equal
+        # similarities: the exposed part of the row sort is k_rank_rows_tied, reported in kernels_ms_per_step)
+        out["configs4_64k_f32"] = side_job(64000, True, 2, 1)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             work = tempfile.mkdtemp(prefix="hicbench_cpu_")
@@ -413,6 +516,7 @@ def main():
             try:
                 with contextlib.redirect_stdout(io.StringIO()):
                     out["e2e"] = e2e_cli(2000, work)
+                    out["e2e_16k_cached"] = e2e_cli_cached(16000, work, dev)
             except SystemExit:
                 out["e2e"] = None
             shutil.rmtree(work, ignore_errors=True)

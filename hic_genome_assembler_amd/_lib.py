@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhicmi.so")
+LIB_PATH = os.environ.get("HICMI_LIB") or os.path.join(_HERE, "libhicmi.so")     # HICMI_LIB: another build (A/B runs)
 _lib = None
 
 c_i64 = ctypes.c_int64

@@ -43,11 +43,12 @@ namespace hicmi { int set_error(int code, const char* msg) { return fail(code, "
 
 enum Family { F_ROW_SUMS, F_BUILD_W, F_NNCHAIN, F_SORT, F_RANK_INVERT, F_CUT_COUNT, F_HYPER_FLAGS, F_P2_SELECT,
               F_P2_TOTAL, F_P2_SCORE, F_P2_EXACT, F_P2_INSERT, F_P2_WINDOW_G, F_P2_WINDOW_DELTA, F_PLOT, F_PRESORT, F_RANK_RELABEL,
-              F_RANK_TIED, F_COUNT };
+              F_RANK_TIED, F_P2_WINDOW_FLOPS, F_COUNT };
 static const char* kFamilyNames[F_COUNT] = {"row_sums", "build_w", "nnchain", "sort_rows", "rank_invert",
                                             "cut_count", "hyper_flags", "p2_select", "p2_total", "p2_score",
                                             "p2_score_exact", "p2_score_insert", "p2_window_G", "p2_window_delta", "plot",
-                                            "presort_rows", "rank_relabel", "rank_rows_tied"};
+                                            "presort_rows", "rank_relabel", "rank_rows_tied",
+                                            "p2_window_G_flops"};      // (its "bytes" are FLOPS of the window tables' GEMM)
 
 constexpr int kBaseSlabs = 256;                        // partial sums of the closed-form BASE term (one slab per workgroup)
 
@@ -640,7 +641,7 @@ static int start_presort(hicmi_ctx* c)
     HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     HIPCHK(hipMemsetAsync(c->d_ties, 0, 16 + (size_t)n, c->stream2));
     {
-        Timed t(c, F_PRESORT, (8.0 + 2.0 + 2.0 + 2.0) * (double)n * (double)n, c->stream2);
+        Timed t(c, F_PRESORT, (8.0 + 2.0) * (double)n * (double)n, c->stream2);      // N^2 (e + idx) for the row argsort
         SortExtras x;
         x.tie_count = reinterpret_cast<unsigned*>(c->d_ties); x.tie_flag = c->d_ties + 16;
         x.tie_limit = (unsigned)n;                                 // (never gives up: tied rows are finished by k_rank_rows_tied)
@@ -1427,7 +1428,7 @@ int window_batch(hicmi_ctx* c, int64_t first0, int64_t count, int64_t k, double*
     HIPCHK(hipSetDevice(c->device));
     const int64_t n_cand = c->n_orders * c->n_orients;
     std::vector<WindowBatchEntry> wb((size_t)count);
-    int64_t g_total = 0; int max_m = 0; double g_bytes = 0.0, d_bytes = 0.0;
+    int64_t g_total = 0; int max_m = 0; double g_bytes = 0.0, d_bytes = 0.0, g_flops = 0.0;
     for (int64_t wdx = 0; wdx < count; wdx++) {
         const int64_t first = first0 + wdx;
         WindowBatchEntry& e = wb[(size_t)wdx];
@@ -1444,6 +1445,7 @@ int window_batch(hicmi_ctx* c, int64_t first0, int64_t count, int64_t k, double*
         g_total += (int64_t)e.m * e.m;
         max_m = std::max(max_m, e.m);
         g_bytes += 8.0 * (double)e.m * (double)(c->n_arr - e.m);
+        g_flops += 2.0 * (double)e.m * (double)e.m * (double)(c->n_arr - e.m);       // A (m x (n - m)) . Toeplitz ((n - m) x m), all scaffolds of the window
         d_bytes += 8.0 * (double)n_cand * (0.5 * (double)e.m * (double)(e.m - 1) + (double)e.m);
     }
     // placement tables (k_part2_window.hip) unless the direct per-candidate kernels are asked for (A/B switch)
@@ -1460,6 +1462,7 @@ int window_batch(hicmi_ctx* c, int64_t first0, int64_t count, int64_t k, double*
     {
         // the G and delta kernels are launched as a pair; their algorithmic bytes are booked separately
         c->launches[F_P2_WINDOW_DELTA]++; c->bytes[F_P2_WINDOW_DELTA] += d_bytes;
+        if (!direct) { c->launches[F_P2_WINDOW_FLOPS]++; c->bytes[F_P2_WINDOW_FLOPS] += g_flops; }   // (flops of the GEMM form: bench.py's `mfma`)
         Timed t(c, F_P2_WINDOW_G, g_bytes);
         if (direct)
             launch_p2_window_batch(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, (int)k, c->d_wb, (int)count, max_m, c->d_orders,

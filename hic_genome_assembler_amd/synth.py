@@ -177,9 +177,11 @@ def sparsify(contacts: np.ndarray, zero_fraction: float, decimals: int) -> np.nd
     return np.ascontiguousarray(c)
 
 
-def write_hicpro(out_dir: str, layout: Layout, contacts: np.ndarray, prefix: str = "synth",
+def write_hicpro(out_dir: str, layout: Layout, contacts, prefix: str = "synth",
                  nan_bias_bins=()) -> dict:
     """Write ``.bed``, ``.biases``, ``.matrix`` (upper-triangle triplets) and the scaffold size file.
+    ``contacts=None``: a one-line placeholder ``.matrix`` (for runs that read the matrix from its binary cache,
+    hostio.read_contact_matrix_cached - a 16,000-bin text file has 128 M lines).
 
     Formats follow what the reference's loaders read (scaffoldToChromosomes.py:35-98, 968-979).
     Returns the four paths keyed by the reference's config-variable names.
@@ -204,7 +206,9 @@ def write_hicpro(out_dir: str, layout: Layout, contacts: np.ndarray, prefix: str
         for k in range(n):
             fh.write("nan\n" if int(ids[k]) in nan_bias else repr(float(bias[k])) + "\n")
     with open(paths["hicProMatrixFile"], "w") as fh:
-        for i in range(n):
+        if contacts is None:
+            fh.write("%d\t%d\t1.0\n" % (ids[0], ids[0]))
+        for i in range(n if contacts is not None else 0):
             row = contacts[i]
             fh.write("".join("%d\t%d\t%s\n" % (ids[i], ids[j], repr(float(row[j])))
                              for j in range(i, n) if row[j] != 0.0))

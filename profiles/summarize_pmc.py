@@ -28,9 +28,30 @@ def summarize(directory):
     return dict(sorted(out.items()))
 
 
+def kernel_ms_per_step(stats_csv, prefix, steps):
+    """Total duration of the kernels whose name starts with `prefix` in a rocprofv3 --stats kernel_stats.csv, per step."""
+    total_ns = 0.0
+    with open(stats_csv) as fh:
+        for row in csv.DictReader(fh):
+            name = row["Name"].replace("void ", "").strip()
+            if name.startswith(prefix):
+                total_ns += float(row["TotalDurationNs"])
+    return total_ns / 1e6 / steps
+
+
 if __name__ == "__main__":
     res = {}
     args = sys.argv[1:]
+    meta = {}
+    while args and args[0].startswith("--meta="):        # --meta=key=value ... (the commit the counters were collected at, ...)
+        k, v = args.pop(0)[len("--meta="):].split("=", 1)
+        meta[k] = v
+    if args and args[0].startswith("--stats="):          # --stats=kernel_stats.csv:steps -> k_win_outside_mfma ms per step
+        path, steps = args.pop(0)[len("--stats="):].rsplit(":", 1)
+        if os.path.exists(path):
+            meta["k_win_outside_mfma_ms_per_step"] = kernel_ms_per_step(path, "hicmi::k_win_outside_mfma", int(steps))
+    if meta:
+        res["_meta"] = meta
     if args and args[0] == "--any":            # any counters: the directory name ends in _<COUNTER>; values summed per kernel
         for directory in args[1:]:
             if not os.path.isdir(directory):
