@@ -325,6 +325,11 @@ class Job:
                                self.lay.resolution, shard=self.shard, chromosomeList=dm.chromosome_groups,
                                on_native_phase=dm.release_files)
             dm.finish_files()
+            if self.shard is not None and not a.part1_only:
+                groups = dm.chromosome_groups
+                mine = p2.chromosomesOfRank(groups, self.shard[0], self.shard[1])
+                self.last["my_chromosomes"] = [int(i) for i in mine]
+                self.last["my_load"] = int(sum(len(groups[i]) ** 2 for i in mine))
         self.last["part2_s"] = time.perf_counter() - ta - self.last["part1_s"]
         self.last["cuts"] = cuts
         self.parts[0] += self.last["part1_s"]; self.parts[1] += self.last["part2_s"]; self.parts[2] += 1
@@ -429,8 +434,12 @@ def main():
     from hic_genome_assembler_amd import orderGenome as p2
 
     n = args.bins
+    # Part 1's per-row stages are row-sharded over the ranks when asked for, and by themselves where they are worth an
+    # all-gather per scan: maps whose every row holds equal similarities (fp32 contacts: k_rank_rows_tied is exposed after
+    # the chain) and 48,000 bins or more (the counts of a scan are ~25 ms per map there) - DESIGN.md section 7
+    shard_p1 = one_map and (args.shard_part1 or args.f32 or n >= 48000)
     job = Job(args, n, dev, local, map_seed, shard, f32=args.f32)
-    if not args.shard_part1:
+    if not shard_p1:
         job.shard_p1 = None
     timing_mode = 0 if os.environ.get("HICMI_BENCH_NO_TIMING") else (1 if args.kernel_times == "all" else 2)
     # HIP events around the families that decide the roofline line (nn-chain, row sort, ...).  --kernel-times all
@@ -463,7 +472,7 @@ def main():
                        "part2_workers": p2.WORKERS, "ranks": world,
                        "parallelism": (("ONE map over %d ranks: Part 1's row-independent stages (row sums, rank rows, cut and "
                                         "filter counts) row-sharded with an all-gather of the per-row flags per scan, UPGMA "
-                                        "replicated, Part 2's chromosomes dealt to the ranks" % world) if args.shard_part1 else
+                                        "replicated, Part 2's chromosomes dealt to the ranks" % world) if shard_p1 else
                                        ("ONE map over %d ranks: Part 1 on every rank (no collective), Part 2's chromosomes "
                                         "dealt to the ranks, one all-gather of the ordered lists" % world)) if one_map
                                       else "1 independent map per rank, no collective" if world > 1 else "single GPU"},
@@ -471,6 +480,21 @@ def main():
             "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in timing.items()
                                     if v["ms"] > 0 or args.kernel_times == "all"},
         }
+    if world > 1:
+        # the record explains its own curve: what every rank spent where, and how Part 2's chromosomes were dealt
+        from hic_genome_assembler_amd import orderGenome as _p2
+        mine = {"part1_s_per_step": round(job.parts[0] / max(job.parts[2], 1), 4),
+                "part2_s_per_step": round(job.parts[1] / max(job.parts[2], 1), 4),
+                "chromosomes": job.last.get("my_chromosomes"), "bins_squared_load": job.last.get("my_load")}
+        per_rank = dist.gather_results({rank: mine})
+        if rank == 0:
+            import torch.distributed as tdist
+            loads = [per_rank[r]["bins_squared_load"] or 0 for r in sorted(per_rank)]
+            out["multi_gpu"] = {"rccl_ranks": tdist.get_world_size(), "backend": tdist.get_backend(),
+                                "per_rank": {str(r): per_rank[r] for r in sorted(per_rank)},
+                                "part2_load_imbalance_max_over_mean": (max(loads) / (sum(loads) / len(loads))) if sum(loads) else None,
+                                "part1": "row-sharded (one all-gather of the owned flags per scan)" if shard_p1 else
+                                         "replicated on every rank (the chain does not shard: DESIGN.md section 7)"}
     if world == 1 and not args.no_table:
         # one more step, untimed, with events around EVERY launch: the per-kernel roofline table
         _e, t_all, _s = timed_run(job, 1, 0, 1, dist.barrier, reduce_dev)

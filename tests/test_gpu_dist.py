@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, tmp_root, name):
+def _worker(rank, world, port, tmp_root, name, backend="gloo"):
     import contextlib
     import io
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
@@ -28,7 +28,14 @@ def _worker(rank, world, port, tmp_root, name):
     from hic_genome_assembler_amd import _lib, dist, orderGenome as p2, scaffoldToChromosomes as p1
     from hic_genome_assembler_amd.hostio import initiateLoci
     _lib.load()                                                   # the HIP library or nothing
-    dist.init("gloo")
+    device = 0
+    if backend == "nccl":                                         # one GPU per rank: RCCL carries the all-gathers as device tensors
+        import torch
+        device = rank
+        torch.cuda.set_device(device)
+        dist.init("nccl", device=torch.device("cuda", device))
+    else:
+        dist.init("gloo")
     import numpy as np
     seen = {"scans": 0, "foreign_nonzero": 0}
     inner_cut, inner_filter = _lib.Context.cut_scan, _lib.Context.filter_scan
@@ -61,11 +68,11 @@ def _worker(rank, world, port, tmp_root, name):
         p1.runPipeline(paths["hicProBedFile"], paths["hicProBiasFile"], paths["hicProMatrixFile"],
                        paths["hicProScaffSizeFile"], f("dendrogramOrder.txt"), f("a.png"), f("b.png"),
                        f("binGroups.txt"), f("assessment.txt"), f("chromosomeGroups.txt"),
-                       True, False, spec["min_size"], 0.0, 20, spec["psig"], 5, .2, 100000, shard=(rank, world))
+                       True, False, spec["min_size"], 0.0, 20, spec["psig"], 5, .2, 100000, device=device, shard=(rank, world))
         chroms = p2.readChromsFromFile(f("chromosomeGroups.txt"))
         binDict = p2.readGroupingsToValidBins(f("chromosomeGroups.txt"))
         binList = initiateLoci(paths["hicProBedFile"], paths["hicProBiasFile"], binID_dict=binDict)
-        adj = p2.buildAdjacencyMatrix(paths["hicProMatrixFile"], binList)
+        adj = p2.buildAdjacencyMatrix(paths["hicProMatrixFile"], binList, device=device)
         try:
             ordered = p2.runResident(adj, binList, f("chromosomeGroups.txt"), f("chromosomeOrders.txt"),
                                      f("plotOrder.txt"), spec["n_scaffolds"], spec["scan_scaffolds"], 100000,
@@ -99,3 +106,19 @@ def test_one_map_sharded_over_two_ranks_on_the_gpu(tmp_path, name):
         assert text == gc.golden_text(name, fn), fn
     a, b = got["deals"]["0"], got["deals"]["1"]
     assert a and b and not set(a) & set(b)
+
+
+def test_one_map_sharded_over_two_gpus_with_rccl(tmp_path):
+    """The same flow with one GPU per rank and backend "nccl" (= RCCL): dist.gather_owned's all_gather_into_tensor runs on
+    DEVICE tensors over xGMI, the time reduction and the barrier are RCCL collectives.  Needs two visible GPUs: the 1-GPU
+    boxes this suite usually runs on skip it; the first multi-GPU box exercises it."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL all_gather_into_tensor on device tensors)")
+    name = "n600"
+    port = 29800 + (os.getpid() % 90)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), name, "nccl"), nprocs=2, join=True)
+    with open(tmp_path / "sharded.json") as fh:
+        got = json.load(fh)
+    for fn, text in got["files"].items():
+        assert text == gc.golden_text(name, fn), fn
