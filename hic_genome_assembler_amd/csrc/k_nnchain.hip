@@ -786,7 +786,9 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_nc(double* __restrict__
     }
 }
 
-// ---- the same chain on several workgroups (k_nn_epoch_mw) -----------------------------------------------
+// ---- the same chain on several workgroups: protocol and helpers ------------------------------------------
+// (k_nn_epoch_mw, the cache-less sliced kernel of round 1 this text was written for, is gone: k_nn_epoch_mwc and
+//  k_nn_epoch_w1 below keep its protocol.)
 // A lone CU streams a row at ~77 GB/s: at 16k bins a 128 KB scan is two thirds transfer, one third latency.
 // Here NWG workgroups (one CU each, any XCD) run the SAME chain as replicated state machines: each keeps the
 // full LDS state (liveness, sizes, dirty list, chain) and takes every decision itself, but streams only ITS
@@ -844,324 +846,9 @@ __device__ __forceinline__ double2 mw_pair(u32x4 r)
 
 // A 16-byte sc1 store may land as two 8-byte halves, so each half carries the sequence number itself:
 //   {value bits 31..0, seq} {value bits 63..32, index | (seq & 0x7fff) << 17}     (index < 2^17; 0x1ffff = none)
-__device__ __forceinline__ u32x4 mw_pack(double v, int idx, unsigned int seq)
-{
-    u32x4 p;
-    p.x = (unsigned int)__double2loint(v); p.y = seq;
-    p.z = (unsigned int)__double2hiint(v);
-    p.w = ((unsigned int)(idx < 0x1ffff ? idx : 0x1ffff)) | ((seq & 0x7fffu) << 17);
-    return p;
-}
-__device__ __forceinline__ bool mw_ready(u32x4 p, unsigned int seq) { return p.y == seq && (p.w >> 17) == (seq & 0x7fffu); }
 __device__ __forceinline__ double mw_value(u32x4 p) { return __hiloint2double((int)p.z, (int)p.x); }
-__device__ __forceinline__ int mw_index(u32x4 p) { const int i = (int)(p.w & 0x1ffffu); return i == 0x1ffff ? 0x7fffffff : i; }
 
-template <int NWG>
-__global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mw(double* __restrict__ W, int64_t ld, int n,
-                                                            int* __restrict__ chain_all, double* __restrict__ zraw,
-                                                            NNWorkspace w, int dcap, int total_steps)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_nn[];
-    const int nwords = (n + 31) >> 5, nw4 = (nwords + 3) & ~3;
-    uint32_t* alive = reinterpret_cast<uint32_t*>(smem_nn);
-    uint32_t* smask = alive + nw4;
-    uint16_t* lsize = reinterpret_cast<uint16_t*>(smask + nw4);
-    __shared__ int dslot[NN_DMAX], dtime[NN_DMAX];
-    __shared__ double s_v[16];
-    __shared__ int s_i[16];
-    __shared__ int ring[256];
-    __shared__ double s_dprev, s_fresh;
-    __shared__ int s_x, s_prev, s_done, s_stop, s_mx, s_my, s_nx, s_ny, s_tx, s_ty, s_ey, s_nextx, s_fresh_x, s_fresh_y, s_fresh_tag,
-        s_fresh_local, s_late;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
-    int* __restrict__ chain = chain_all + (int64_t)wg * (n + 2);           // every workgroup keeps its own copy
-    u32x4* mail = reinterpret_cast<u32x4*>(w.mail);
-    u32x4* fresh_slot = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(w.state) + 128);
-    int step = w.state[0];
-    if (step >= total_steps || w.state[5]) {
-        if (tid == 0 && wg == 0) w.state[6] = 0;
-        return;
-    }
-    // column slice of this workgroup: multiples of 64 so that mask words and 16-byte loads never straddle
-    const int slice = (((n + NWG - 1) / NWG) + 63) & ~63;
-    const int c0 = wg * slice < n ? wg * slice : n;
-    const int c1 = c0 + slice < n ? c0 + slice : n;
-    for (int i = tid; i < nwords; i += NN_THREADS) { alive[i] = w.alive[i]; smask[i] = w.alive[i]; }
-    for (int i = tid; i < n; i += NN_THREADS) lsize[i] = w.size[i];
-    int len = w.state[1], top = w.state[2], second = w.state[3], first_ptr = w.state[4], ring_lo = len;
-    if (tid == 0) { s_stop = 0; s_done = 0; s_fresh_x = -1; s_fresh_y = -1; s_fresh_tag = 0; s_fresh_local = 0; s_late = 0; }
-    // the chain prefix of the earlier epochs (saved by workgroup 0) is read from workgroup 0's copy
-    const int* __restrict__ chain0 = chain_all;
-    __syncthreads();
-    int D = 0;
-    uint32_t xbit = 0u;
-    unsigned int xseq = 0u;                                  // exchanges so far (uniform)
-    unsigned long long tp[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
-    const bool prof = w.state[8] != 0 && wg == 0 && tid == 0;
-    int lowmark = len;                                       // lane 0: chain entries below this are still the earlier epochs'
-    const int step0 = step;                                  // records of this epoch: w.rec[(wg * NN_DMAX + step - step0) * 4 ..]
-    const int inject_late = w.state[10], inject_wrong = w.state[11];      // test hooks (0 = off)
-    unsigned long long c_cols = 0, c_scans = 0;
-    if (tid == 0 && wg == 0) w.state[9] = step0;
-
-    for (; step < total_steps && D < dcap; step++) {
-        if (prof) t0 = wall_clock64();
-        if (tid == 0 && len == 0) {
-            while (first_ptr < n && !((alive[first_ptr >> 5] >> (first_ptr & 31)) & 1u)) first_ptr++;
-            chain[0] = first_ptr; ring[0] = first_ptr; ring_lo = 0; top = first_ptr; second = -1; len = 1;
-        }
-        int guard = 0;
-        double cur = 0.0;
-        int ybest = -1;
-        while (true) {
-            if (tid == 0) {
-                s_x = top; s_prev = (len > 1) ? second : -1; s_tx = -1;
-                xbit = smask[top >> 5] & (1u << (top & 31));
-                smask[top >> 5] &= ~xbit;
-                c_scans++; c_cols += (unsigned long long)(total_steps + 1 - step);
-            }
-            __syncthreads();
-            const int x = s_x, prev = s_prev;
-            if (tid < D && dslot[tid] == x) s_tx = dtime[tid];
-            __syncthreads();
-            if (prof) { t1 = wall_clock64(); tp[0] += t1 - t0; t0 = t1; }
-            const int tx = s_tx;
-            const double* __restrict__ rowx = W + (int64_t)x * ld;
-            const bool use_fresh = (s_fresh_x == x);
-            const int fresh_y = s_fresh_y;
-            if (tid == 64 && prev >= 0 && ((smask[prev >> 5] >> (prev & 31)) & 1u)) s_dprev = ld8_sc1(rowx + prev);
-            ArgMin cand = {__builtin_inf(), 0x7fffffff};
-            if (tid < D) {
-                const int d = dslot[tid];
-                if (d >= 0 && d != x && ((alive[d >> 5] >> (d & 31)) & 1u)) {
-                    const bool mine = d >= c0 && d < c1;
-                    if (mine || d == prev) {
-                        double v;
-                        if (use_fresh && d == fresh_y) {                     // merged a moment ago: no exchange since
-                            if (s_fresh_local) v = s_fresh;
-                            else {
-                                const unsigned int tag = (unsigned int)s_fresh_tag;
-                                u32x4 r = ld16_sc1(fresh_slot);
-                                int budget = 1000000;
-                                while (!mw_ready(r, tag) && --budget > 0) { __builtin_amdgcn_s_sleep(1); r = ld16_sc1(fresh_slot); }
-                                if (!mw_ready(r, tag)) s_late = 1;
-                                v = mw_value(r);
-                            }
-                        }
-                        else v = dtime[tid] > tx ? ld8_sc1(W + (int64_t)d * ld + x) : ld8_sc1(rowx + d);
-                        if (mine) { cand.v = v; cand.i = d; }
-                        if (d == prev) s_dprev = v;
-                    }
-                }
-            }
-            ArgMin best = {__builtin_inf(), 0x7fffffff};
-            for (int j0 = c0 + tid * 2; j0 < c1; j0 += 4 * NN_THREADS) {    // two 16-byte loads in flight per lane
-                const int j1 = j0 + 2 * NN_THREADS;
-                const bool two = j1 < c1;
-                u32x4 r0, r1;
-                NN_LD16_SC1(r0, rowx + j0);
-                NN_LD16_SC1(r1, rowx + (two ? j1 : j0));
-                NN_DRAIN2(r0, r1);
-                {
-                    const double2 v = mw_pair(r0);
-                    const uint32_t bits = smask[j0 >> 5] >> (j0 & 31);
-                    if ((bits & 1u) && v.x < best.v) { best.v = v.x; best.i = j0; }
-                    if ((bits & 2u) && v.y < best.v) { best.v = v.y; best.i = j0 + 1; }
-                }
-                if (two) {
-                    const double2 v = mw_pair(r1);
-                    const uint32_t bits = smask[j1 >> 5] >> (j1 & 31);
-                    if ((bits & 1u) && v.x < best.v) { best.v = v.x; best.i = j1; }
-                    if ((bits & 2u) && v.y < best.v) { best.v = v.y; best.i = j1 + 1; }
-                }
-            }
-            if (cand.v < best.v || (cand.v == best.v && cand.i < best.i)) best = cand;
-            best = argmin_wave(best);
-            if (lane == 0) { s_v[wave] = best.v; s_i[wave] = best.i; }
-            __syncthreads();
-            if (prof) { t1 = wall_clock64(); tp[1] += t1 - t0; t0 = t1; }
-            xseq++;
-            if (wave == 0) {
-                ArgMin m = {lane < 16 ? s_v[lane] : __builtin_inf(), lane < 16 ? s_i[lane] : 0x7fffffff};
-                m = argmin_row16(m);                                // this slice's result, in every lane of row 0
-                u32x4* slots = mail + (xseq & 1u) * NN_MAXWG;
-                if (lane == 0) st16_sc1(slots + wg, mw_pack(m.v, m.i, xseq));
-                ArgMin o = {__builtin_inf(), 0x7fffffff};
-                int late = 0;
-                if (lane < NWG) {
-                    if (lane == wg) o = m;
-                    else {
-                        u32x4 r = ld16_sc1(slots + lane);
-                        int budget = 1000000;
-                        while (!mw_ready(r, xseq) && --budget > 0) { __builtin_amdgcn_s_sleep(1); r = ld16_sc1(slots + lane); }
-                        if (!mw_ready(r, xseq)) late = 1;
-                        o.v = mw_value(r); o.i = mw_index(r);
-                    }
-                }
-                if (inject_late > 0 && (int)xseq == inject_late) late = 1;      // test hook: a peer that never answers
-                late = __any(late);
-                m = argmin_row16(o);
-                if (lane == 0) {
-                    int y; double c;
-                    if (prev >= 0) {
-                        double dprev = s_dprev;
-                        if (m.v < dprev) { y = m.i; c = m.v; } else { y = prev; c = dprev; }
-                    } else { y = m.i; c = m.v; }
-                    int done = (prev >= 0 && y == prev);
-                    if (late || s_late) { s_stop = NN_STOP_LATE; done = 1; }
-                    else if (y < 0 || y >= n || ++guard > n + 2) { s_stop = NN_STOP_GUARD; done = 1; }
-                    else if (!done) {
-                        chain[len] = y; ring[len & 255] = y;
-                        if (len - 255 > ring_lo) ring_lo = len - 255;
-                        second = top; top = y; len++;
-                    }
-                    cur = c; ybest = y;
-                    smask[x >> 5] |= xbit;
-                    s_done = done;
-                    s_fresh_x = -1;                                 // an exchange has happened: memory is current
-                }
-            }
-            __syncthreads();
-            if (prof) { t1 = wall_clock64(); tp[2] += t1 - t0; t0 = t1; }
-            if (s_done) break;
-        }
-        if (s_stop) break;
-        if (tid == 0) {
-            int xx = s_x, yy = ybest;
-            len -= 2;
-            if (xx > yy) { int t = xx; xx = yy; yy = t; }
-            int nx = lsize[xx], ny = lsize[yy];
-            if (wg == 0) {
-                zraw[4 * (int64_t)step + 0] = (double)xx;
-                zraw[4 * (int64_t)step + 1] = (double)yy;
-                zraw[4 * (int64_t)step + 2] = cur;
-                zraw[4 * (int64_t)step + 3] = (double)(nx + ny);
-            }
-            {   // every replica takes every decision: its own record of the merge, compared by k_nn_check_replicas
-                double* r = w.rec + ((int64_t)wg * NN_DMAX + (step - step0)) * 4;
-                r[0] = (double)xx; r[1] = (double)yy; r[3] = (double)(nx + ny);
-                r[2] = (inject_wrong > 0 && wg == 1 && step == inject_wrong) ? cur + 1.0 : cur;
-            }
-            lsize[xx] = 0;
-            lsize[yy] = (uint16_t)(nx + ny);
-            alive[xx >> 5] &= ~(1u << (xx & 31));
-            smask[xx >> 5] &= ~(1u << (xx & 31));
-            s_mx = xx; s_my = yy; s_nx = nx; s_ny = ny; s_tx = -1; s_ty = -1; s_ey = -1;
-            // entries no push of this epoch has overwritten live in workgroup 0's copy (saved by the last epoch)
-            if (len < lowmark) lowmark = len;
-            const int i1 = len - 1, i2 = len - 2;
-            top = len >= 1 ? (i1 >= ring_lo ? ring[i1 & 255] : (i1 < lowmark ? chain0[i1] : chain[i1])) : -1;
-            second = len >= 2 ? (i2 >= ring_lo ? ring[i2 & 255] : (i2 < lowmark ? chain0[i2] : chain[i2])) : -1;
-            // the row the next scan visits (its d(., y') is needed before any exchange)
-            int nextx = top;
-            if (len == 0) {
-                int fp = first_ptr;
-                while (fp < n && !((alive[fp >> 5] >> (fp & 31)) & 1u)) fp++;
-                nextx = fp < n ? fp : -1;
-            }
-            s_nextx = nextx;
-        }
-        __syncthreads();
-        const int mx = s_mx, my = s_my;
-        if (tid < D) {
-            if (dslot[tid] == mx) s_tx = dtime[tid];
-            if (dslot[tid] == my) { s_ty = dtime[tid]; s_ey = tid; }
-        }
-        __syncthreads();
-        if (prof) { t1 = wall_clock64(); tp[3] += t1 - t0; t0 = t1; }
-        {
-            const int tmx = s_tx, tmy = s_ty, nextx = s_nextx;
-            const double fx = (double)s_nx, fy = (double)s_ny, fs = (double)(s_nx + s_ny);
-            const double rcp = 1.0 / fs;
-            const double* __restrict__ rx = W + (int64_t)mx * ld;
-            double* __restrict__ ry = W + (int64_t)my * ld;
-            double dv = 0.0; int dd = -1;
-            double fresh_out = __builtin_nan("");              // the owner of column nextx hands W[y'][nextx] on
-            bool have_fresh = false;
-            if (tid < D) {
-                const int d = dslot[tid];
-                if (d >= 0 && d != my && ((alive[d >> 5] >> (d & 31)) & 1u)) {
-                    if (d >= c0 && d < c1) {                          // columns of this slice only: rx[d], ry[d] are its own
-                        const double dxi = dtime[tid] > tmx ? ld8_sc1(W + (int64_t)d * ld + mx) : ld8_sc1(rx + d);
-                        const double dyi = dtime[tid] > tmy ? ld8_sc1(W + (int64_t)d * ld + my) : ld8_sc1(ry + d);
-                        dv = div_by_small_int(fx * dxi + fy * dyi, fs, rcp);
-                        dd = d;
-                        if (d == nextx) { fresh_out = dv; have_fresh = true; }
-                    }
-                }
-            }
-            for (int j0 = c0 + tid * 2; j0 < c1; j0 += 4 * NN_THREADS) {
-                const int j1 = j0 + 2 * NN_THREADS;
-                const bool two = j1 < c1;
-                u32x4 ra0, rb0, ra1, rb1;
-                NN_LD16_SC1(ra0, rx + j0);
-                NN_LD16_SC1(rb0, ry + j0);
-                NN_LD16_SC1(ra1, rx + (two ? j1 : j0));
-                NN_LD16_SC1(rb1, ry + (two ? j1 : j0));
-                NN_DRAIN4(ra0, rb0, ra1, rb1);
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    if (h == 1 && !two) break;
-                    const int j = h ? j1 : j0;
-                    const double2 a = mw_pair(h ? ra1 : ra0);
-                    double2 b = mw_pair(h ? rb1 : rb0);
-                    const uint32_t bits = smask[j >> 5] >> (j & 31);
-                    if ((bits & 1u) && j != my) b.x = div_by_small_int(fx * a.x + fy * b.x, fs, rcp);
-                    if ((bits & 2u) && j + 1 != my) b.y = div_by_small_int(fx * a.y + fy * b.y, fs, rcp);
-                    if (j == nextx && (bits & 1u)) { fresh_out = b.x; have_fresh = true; }
-                    if (j + 1 == nextx && (bits & 2u)) { fresh_out = b.y; have_fresh = true; }
-                    u32x4 pk;
-                    pk.x = (unsigned int)__double2loint(b.x); pk.y = (unsigned int)__double2hiint(b.x);
-                    pk.z = (unsigned int)__double2loint(b.y); pk.w = (unsigned int)__double2hiint(b.y);
-                    st16_sc1(ry + j, pk);
-                }
-            }
-            if (have_fresh && nextx != my) {
-                st16_sc1(fresh_slot, mw_pack(fresh_out, 0, (unsigned int)(step + 1)));
-                s_fresh = fresh_out;
-            }
-            // the pair stores above are inline assembly the compiler's wait-count pass does not see: drain them before
-            // the barrier, or a dirty column's 8-byte store below could be overtaken by the pair store that still
-            // carries its old value
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (dd >= 0) st8_sc1(ry + dd, dv);
-            if (tid == 0) {
-                if (s_ey >= 0) dslot[s_ey] = -1;
-                dslot[D] = my; dtime[D] = step;
-                smask[my >> 5] &= ~(1u << (my & 31));
-                s_fresh_x = (nextx >= 0 && nextx != my) ? nextx : -1;
-                s_fresh_y = my;
-                s_fresh_tag = step + 1;
-                s_fresh_local = (nextx >= c0 && nextx < c1) ? 1 : 0;
-            }
-            D++;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains before the next exchange signals
-        __syncthreads();
-        if (prof) { t1 = wall_clock64(); tp[4] += t1 - t0; }
-    }
-    __syncthreads();
-    if (wg != 0) return;
-    // chain entries this epoch wrote into a private copy: workgroup 0's copy is the one the next epoch reads
-    for (int i = tid; i < nwords; i += NN_THREADS) w.alive[i] = alive[i];
-    for (int i = tid; i < n; i += NN_THREADS) { w.size[i] = lsize[i]; w.gtime[i] = -1; }
-    __syncthreads();
-    if (tid < D) {
-        w.dslot[tid] = dslot[tid]; w.dtime[tid] = dtime[tid];
-    }
-    __syncthreads();
-    if (tid < D && dslot[tid] >= 0) w.gtime[dslot[tid]] = dtime[tid];
-    if (tid == 0) {
-        w.state[0] = step; w.state[1] = len; w.state[2] = top; w.state[3] = second; w.state[4] = first_ptr;
-        w.state[5] = s_stop; w.state[6] = D;
-        w.prof[5] += c_cols; w.prof[6] += c_scans;
-        if (prof) for (int q = 0; q < 5; q++) w.prof[q] += tp[q];
-    }
-}
-
-// Every replica of k_nn_epoch_mw decides every merge itself from values that crossed workgroups through sc1 accesses
+// Every replica of k_nn_epoch_mwc decides every merge itself from values that crossed workgroups through sc1 accesses
 // (measured behaviour, not an architectural guarantee: MI355X_MICROARCH.md).  A stale read would show up as replicas
 // that disagree - so their records of the epoch are compared, and a difference stops the chain with an error
 // instead of returning a wrong tree.
@@ -1916,7 +1603,8 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
     if (lane == 0 && wg == 0) w.state[9] = step0;
     __syncthreads();
 
-    int tl = 0;                                              // merges of this epoch so far: the local clock
+    int tl = 0;                                              // the local clock: merges since the time stamps were last renormalised
+    int done_e = 0;                                          // merges of this epoch so far
     int lowmark = len;                                       // chain entries below this are still the earlier epochs'
     unsigned int xseq = (unsigned int)w1_uni(w.state[14]);   // exchanges so far in this map: the mailboxes are cleared once per map
     const unsigned int xseq0 = xseq;
@@ -1986,7 +1674,28 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
         return __any(late) ? 1 : 0;
     };
 
-    for (; step < total_steps && tl < dcap; step++) {
+    for (; step < total_steps && done_e < dcap; step++) {
+        if (tl >= NN_W1_DCAP) {
+            // The 8-bit times are about to run out: settle the cache in place (what k_nn_settle does between epochs) - stale
+            // entries become "unknown", the others restart at stamp 0, every slot's merge time at 0.  ~8 us per 252 merges;
+            // an epoch boundary (state out, three launches, state in on 64 workgroups) costs ~100 us, so an epoch now runs
+            // until the next compaction is due instead of 252 merges.
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) {
+                const uint32_t e = meta[i];
+                const uint32_t idx = e & W1_NOIDX;
+                bool ok = false;
+                if (idx != W1_NOIDX && (int)idx < n) { const uint32_t mt = meta[idx] >> 24; ok = mt != 255u && mt <= ((e >> 16) & 0xffu); }
+                if (!ok) meta[i] = e | W1_NOIDX;
+            }
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) {
+                const uint32_t e = meta[i];
+                meta[i] = (e & 0xffffu) | ((e >> 24) == 255u ? 0xff000000u : 0u);
+            }
+            __syncthreads();
+            tl = 0;
+        }
         if (prof) t0 = wall_clock64();
         int act = 0;
         while (true) {
@@ -2202,7 +1911,7 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             __syncthreads();
         }
         // ---- the merged cluster's neighbour is known; the fused scan of row a is decided like a scan on its own
-        tl++;
+        tl++; done_e++;
         if (lane == 0) {
             const bool known = R.i >= 0 && R.i < n;
             meta[my] = (known ? (uint32_t)R.i | ((uint32_t)(R.t ? 1 : 0) << 15) : W1_NOIDX) | ((uint32_t)tl << 16) | ((uint32_t)tl << 24);
@@ -2422,7 +2131,6 @@ static void launch_mwc(int wgs, bool profile, size_t lds, hipStream_t s, double*
         return;
     }
     if (wgs == 16) launch_mwc_n<16>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
-    else if (wgs == 1) launch_mwc_n<1>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
     else if (wgs == 2) launch_mwc_n<2>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
     else if (wgs == 4) launch_mwc_n<4>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
     else launch_mwc_n<8>(profile, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
@@ -2430,8 +2138,7 @@ static void launch_mwc(int wgs, bool profile, size_t lds, hipStream_t s, double*
 
 static void mwc_set_lds(int bytes)
 {
-    const void* fns[] = {reinterpret_cast<const void*>(k_nn_epoch_mwc<1, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<1, true>),
-                         reinterpret_cast<const void*>(k_nn_epoch_mwc<2, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<2, true>),
+    const void* fns[] = {reinterpret_cast<const void*>(k_nn_epoch_mwc<2, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<2, true>),
                          reinterpret_cast<const void*>(k_nn_epoch_mwc<4, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<4, true>),
                          reinterpret_cast<const void*>(k_nn_epoch_mwc<8, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<8, true>),
                          reinterpret_cast<const void*>(k_nn_epoch_mwc<16, false>), reinterpret_cast<const void*>(k_nn_epoch_mwc<16, true>)};
@@ -2544,21 +2251,16 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     // 16 slices instead of 8 while the rows are long: a merge costs ~7.4 / 8.5 / 11.4 us at 2,000 / 4,000 / 8,000 columns per
     // slice, and the sixteen-way exchange only a little more than the eight-way one.  Measured (nn-chain per map, threshold
     // off / 24,000 / 16,000 / 12,000 live columns): 32k 272 / 264 / 256 / 259 ms, 64k 730 / 682 / 678 / - ms, 16k 118.3 / - / - / 116.8
-    const char* w16_text = getenv("HICMI_NNCHAIN_W16_FROM");
-    const int w16_from = wgs_text ? 0x7fffffff : (w16_text ? atoi(w16_text) : 14000);
-    const char* from_text = getenv("HICMI_NNCHAIN_MW_FROM");
+    const int w16_from = wgs_text ? 0x7fffffff : 14000;
     // live columns from which an epoch runs sliced: with the cache and the fused scan a merge costs ~1.3 exchanges instead
     // of ~2.9, so eight slices pay from ~6,000 columns on (16k map: nn-chain 200 -> 153 ms; 4,000 and 8,000 measure the same)
-    const int mw_from = wgs_text ? 64 * wgs : (from_text ? atoi(from_text) : 6000);
+    const int mw_from = wgs_text ? 64 * wgs : 6000;
     const bool plain = getenv("HICMI_NNCHAIN_PLAIN") != nullptr;
-    const bool fused1 = getenv("HICMI_NNCHAIN_FUSED1") != nullptr;       // narrow epochs on k_nn_epoch_mwc<1> instead of k_nn_epoch_nc
-    const bool mw_old = getenv("HICMI_NNCHAIN_MW_OLD") != nullptr;       // k_nn_epoch_mw also where k_nn_epoch_mwc would fit (A/B, tests)
     // Rebuild the whole cache (k_nn_rowmin, a full-chip pass over the flushed matrix: 0.13 ms at 8,000 live columns) before
     // every epoch that has at most this many live columns: rows whose neighbour merged are then known again without a scan
     // of their own.  Worth 1.5 ms per 16k map (scans per merge 1.28 -> 1.23: most such rows are walked within the epoch that
     // invalidated them); above ~12,000 columns the pass costs more than the scans it saves.  0 = never.
-    const char* refresh_text = getenv("HICMI_NNCHAIN_REFRESH");
-    const int refresh_below = refresh_text ? atoi(refresh_text) : 8000;
+    const int refresh_below = 8000;
     const bool force_gsize = getenv("HICMI_NNCHAIN_GSIZE") != nullptr;   // the GSIZE variant of k_nn_epoch_mwc at every width (tests)
     // One wave per column slice (k_nn_epoch_w1): the default at every width up to 32,768 live columns.  HICMI_NNCHAIN_W1=0
     // selects the 1024-lane kernels of rounds 1-2 instead (A/B; so does every switch that names one of them);
@@ -2568,11 +2270,11 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     const char* w1_s_text = getenv("HICMI_NNCHAIN_W1_S");
     const char* w1_cols_text = getenv("HICMI_NNCHAIN_W1_COLS");
     const char* w1_maxs_text = getenv("HICMI_NNCHAIN_W1_MAXS");
-    const bool w1_on = !(w1_text && atoi(w1_text) == 0) && !wgs_text && !force_single && !plain && !fused1 && !mw_old && !force_gsize;
+    const bool w1_on = !(w1_text && atoi(w1_text) == 0) && !wgs_text && !force_single && !plain && !force_gsize;
     const int w1_force_s = w1_s_text ? atoi(w1_s_text) : 0;
     const int w1_cols = w1_cols_text ? (atoi(w1_cols_text) > 64 ? atoi(w1_cols_text) : 64) : 256;
     const int w1_max_s = w1_maxs_text ? atoi(w1_maxs_text) : NN_W1_MAXS;
-    if (w1_on && dcap > NN_W1_DCAP) dcap = NN_W1_DCAP;                   // its dirty list: four entries per lane, 8-bit times
+    const bool dcap_forced = getenv("HICMI_NNCHAIN_DCAP") != nullptr;
     const int gsize_max = (n > NN_MWC_MAX || force_gsize) ? mwc_gsize_max_columns() : 0;
     if (dcap < 1) dcap = 1;
     if (dcap > NN_DMAX) dcap = NN_DMAX;
@@ -2594,9 +2296,6 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
         size_t lds_max = align16((size_t)nw4 * 8 + (size_t)n * 2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mw<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mw<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_mw<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         const int nc = n < NN_NC_MAX ? n : NN_NC_MAX, ncw4 = (((nc + 31) / 32) + 3) & ~3;
         size_t lds_nc = align16((size_t)ncw4 * 12 + (size_t)((nc + 7) & ~7) * 4);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_epoch_nc<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nc);
@@ -2615,15 +2314,22 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
         const bool gsize = wgs_e >= 8 && (n_cur > NN_MWC_MAX || force_gsize) && n_cur <= gsize_max;
         int w1_S = 0, w1_slice = 0; size_t w1_lds = 0;
         bool flush_needed = true;
+        int dcap_e = dcap;                                          // merges of this epoch
         if (w1_on && w1_plan(n_cur, w1_cols, w1_max_s, w1_force_s, &w1_S, &w1_slice, &w1_lds)) {
             if (!cache_valid || (refresh_below > 0 && n_cur <= refresh_below)) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
             cache_valid = true;
-            launch_w1(profile, w1_S, w1_slice, w1_lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+            // the one-wave kernel renormalises its time stamps itself: an epoch runs until the next compaction is due
+            // (a quarter of the live columns have merged away), at least 256 merges; HICMI_NNCHAIN_DCAP still forces a length
+            if (!dcap_forced) {
+                const int until = compact ? (n - done) - (int)(((int64_t)n_cur * 3) / 4) : 4096;
+                dcap_e = until > 256 ? until : 256;
+            }
+            launch_w1(profile, w1_S, w1_slice, w1_lds, s, cur, ldw, n_cur, chain, zraw, w, dcap_e, total_steps);
             hipLaunchKernelGGL(k_nn_settle, dim3((n_cur + 255) / 256), dim3(256), 0, s, w, n_cur);
             hipLaunchKernelGGL(k_nn_check_hashes, dim3(1), dim3(64), 0, s, w, w1_S);
             flush_needed = false;                                   // it keeps the matrix symmetric itself
         }
-        else if (sliced && !plain && !mw_old && (n_cur <= NN_MWC_MAX || gsize)) {
+        else if (sliced && !plain && (n_cur <= NN_MWC_MAX || gsize)) {
             // column slices + neighbour cache + the next scan fused into the update (k_nn_epoch_mwc)
             if (!cache_valid || (refresh_below > 0 && n_cur <= refresh_below)) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
             cache_valid = true;
@@ -2631,22 +2337,6 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
             hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 1152, s);      // mailboxes
             launch_mwc(wgs_e, profile, lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, gsize);
             hipLaunchKernelGGL(k_nn_check_replicas, dim3((NN_DMAX + 255) / 256), dim3(256), 0, s, w, wgs_e);
-        }
-        else if (sliced) {
-            hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 1152, s);      // hand-off slot + mailboxes
-            if (wgs == 2) hipLaunchKernelGGL(k_nn_epoch_mw<2>, dim3(2), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
-            else if (wgs == 4) hipLaunchKernelGGL(k_nn_epoch_mw<4>, dim3(4), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
-            else hipLaunchKernelGGL(k_nn_epoch_mw<8>, dim3(8), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
-            hipLaunchKernelGGL(k_nn_check_replicas, dim3((NN_DMAX + 255) / 256), dim3(256), 0, s, w, wgs > 8 ? 8 : wgs);
-            cache_valid = false;
-        }
-        else if (!plain && fused1 && n_cur <= NN_MWC_MAX) {
-            // one workgroup, but the fused pass of k_nn_epoch_mwc (its exchange degenerates to a store nobody waits for)
-            if (!cache_valid || (refresh_below > 0 && n_cur <= refresh_below)) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
-            cache_valid = true;
-            const size_t lds_c = align16((size_t)nw4 * 12 + (size_t)((n_cur + 7) & ~7) * 4);
-            hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 1152, s);
-            launch_mwc(1, profile, lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
         }
         else if (!plain && n_cur <= NN_NC_MAX) {
             if (!cache_valid || (refresh_below > 0 && n_cur <= refresh_below)) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
@@ -2661,7 +2351,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
             cache_valid = false;
         }
         epochs++;
-        const int did = total_steps - done < dcap ? total_steps - done : dcap;
+        const int did = total_steps - done < dcap_e ? total_steps - done : dcap_e;
         done += did;
         if (done >= total_steps) break;
         if (flush_needed) hipLaunchKernelGGL(k_nn_flush, dim3((n_cur + 255) / 256, dcap), dim3(256), 0, s, cur, ldw, n_cur, w);

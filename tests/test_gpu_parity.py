@@ -114,20 +114,15 @@ def test_upgma_beyond_one_streaming_pass_bit_exact(hic, orc):
     assert np.array_equal(leaves, leaves_o)
 
 
-@pytest.mark.parametrize("kernel", ["mwc", "mw"])
 @pytest.mark.parametrize("wgs", [2, 4, 8, 16])
 @pytest.mark.parametrize("n,seed,dcap", [(130, 1, 7), (600, 2, 64), (1025, 6, 1024), (2500, 7, 1024), (4099, 8, 300)])
-def test_upgma_column_sliced_chain_bit_exact(hic, orc, monkeypatch, n, seed, dcap, wgs, kernel):
-    """The chain as 2, 4, 8 or 16 workgroups (16: k_nn_epoch_mwc only, the width of the epochs with 24,000 live columns or
-    more; the older kernel then runs on 8) that each stream a slice of the columns and exchange their (min, index):
-    k_nn_epoch_mwc (neighbour cache replicated in every workgroup, the next scan fused into the update: the default
-    for the wide epochs up to 32,768 live columns) and k_nn_epoch_mw (one exchange per scan, no cache: wider epochs).
-    Forced here for every epoch that is wide enough.  Run three times: the exchange is timing-dependent, the linkage
-    must not be."""
+def test_upgma_column_sliced_chain_bit_exact(hic, orc, monkeypatch, n, seed, dcap, wgs):
+    """k_nn_epoch_mwc - the chain as 2, 4, 8 or 16 workgroups of 1,024 lanes that each stream a slice of the columns, the
+    neighbour cache replicated in every workgroup, the next scan fused into the update (round 2's default; since round 3
+    what rows beyond 32,767 columns run on, and the A/B partner of the one-wave kernel).  HICMI_NNCHAIN_WGS forces it for
+    every epoch that is wide enough.  Run three times: the exchange is timing-dependent, the linkage must not be."""
     monkeypatch.setenv("HICMI_NNCHAIN_WGS", str(wgs))
     monkeypatch.setenv("HICMI_NNCHAIN_DCAP", str(dcap))
-    if kernel == "mw":
-        monkeypatch.setenv("HICMI_NNCHAIN_MW_OLD", "1")
     rng = np.random.default_rng(seed)
     c = rng.random((n, n)) + 0.01
     c = c + c.T
@@ -234,13 +229,12 @@ def test_upgma_cluster_sizes_in_global_memory_bit_exact(hic, orc, monkeypatch, n
     assert np.array_equal(leaves, leaves_o)
 
 
-def test_upgma_wide_rows_cached_and_uncached_agree_at_40k(hic, orc, monkeypatch):
-    """40,000 bins: the first epochs have more than 32,768 live columns and run on the GSIZE variant of the cached
-    kernel; HICMI_NNCHAIN_MW_OLD=1 runs them on k_nn_epoch_mw (no cache: the round-1 kernel the 64k tests of round 1
-    pinned).  Same merges, and fewer row scans (on uniform random distances the cache saves far less than on Hi-C maps:
-    2.3 scans per merge against 2.9; the 64k bench map runs at 1.28).  The default run is also compared with the CPU
-    oracle's nn-chain (~1.5 min of host time): what every 64,000-bin map starts on is pinned at its own width, not only
-    when forced onto small inputs."""
+def test_upgma_wide_rows_match_the_oracle_at_40k(hic, orc):
+    """40,000 bins: the first epochs have more than 32,767 live columns and run on the GSIZE variant of k_nn_epoch_mwc
+    (cluster sizes in global memory, the cache alone in LDS - what every 64,000-bin map starts on), the later ones on the
+    one-wave kernel.  Against the CPU oracle's nn-chain (~1.5 min of host time), at its own width - not only forced
+    onto small inputs.  On uniform random distances the cache saves less than on Hi-C maps (2.3 row scans per merge
+    against SciPy's 2.9; the 64k bench map runs at 1.28)."""
     import torch
     n = 40000
     g = torch.Generator(device="cuda:0")
@@ -248,19 +242,13 @@ def test_upgma_wide_rows_cached_and_uncached_agree_at_40k(hic, orc, monkeypatch)
     c = torch.rand((n, n), generator=g, device="cuda:0", dtype=torch.float64)
     c = c + c.T + 0.01
     torch.cuda.synchronize()
-    got = []
     with hic.Context(0) as ctx:
         ctx.set_contacts_device(c.data_ptr(), n, keepalive=c)
-        for old in (False, True):
-            if old:
-                monkeypatch.setenv("HICMI_NNCHAIN_MW_OLD", "1")
-            ctx.timing_reset()
-            leaves, _z = ctx.upgma()
-            got.append((np.array(leaves), ctx.raw_merges().copy(), ctx.nnchain_stats()))
-    assert np.array_equal(got[0][1], got[1][1])
-    assert np.array_equal(got[0][0], got[1][0])
-    assert sorted(got[0][0].tolist()) == list(range(n))
-    assert got[0][2]["scans"] < 0.85 * got[1][2]["scans"]
+        ctx.timing_reset()
+        leaves, _z = ctx.upgma()
+        zraw, st = ctx.raw_merges().copy(), ctx.nnchain_stats()
+    assert sorted(leaves.tolist()) == list(range(n))
+    assert st["scans"] < 2.6 * st["merges"]
     host = c.cpu().numpy()
     del c
     torch.cuda.empty_cache()
@@ -271,8 +259,8 @@ def test_upgma_wide_rows_cached_and_uncached_agree_at_40k(hic, orc, monkeypatch)
     del host
     zraw_o = orc.nn_chain_raw(dist)
     del dist
-    assert np.array_equal(got[0][1], zraw_o)
-    assert np.array_equal(got[0][0], orc.leaf_order(orc.label_linkage(zraw_o, n), n))
+    assert np.array_equal(zraw, zraw_o)
+    assert np.array_equal(np.array(leaves), orc.leaf_order(orc.label_linkage(zraw_o, n), n))
 
 
 def test_upgma_column_sliced_chain_default_width_at_scale(hic, orc):
@@ -292,25 +280,6 @@ def test_upgma_without_neighbour_cache_bit_exact(hic, orc, monkeypatch, n, seed,
     """HICMI_NNCHAIN_PLAIN=1: k_nn_epoch, the chain that scans a row at every step like SciPy itself (the A/B partner
     of the default k_nn_epoch_nc, and what tests/test_gpu_scale.py compares the default with at 32k / 64k)."""
     monkeypatch.setenv("HICMI_NNCHAIN_PLAIN", "1")
-    monkeypatch.setenv("HICMI_NNCHAIN_DCAP", str(dcap))
-    rng = np.random.default_rng(seed)
-    c = rng.random((n, n)) + 0.01
-    c = c + c.T
-    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, c)
-    assert np.array_equal(zraw, zraw_o)
-    assert np.array_equal(leaves, leaves_o)
-    ties = rng.integers(1, 4, size=(n, n)).astype(np.float64)
-    ties = np.triu(ties, 1) + np.triu(ties, 1).T + np.eye(n)
-    leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, ties)
-    assert np.array_equal(zraw, zraw_o)
-    assert np.array_equal(leaves, leaves_o)
-
-
-@pytest.mark.parametrize("n,seed,dcap", [(5, 0, 1024), (65, 4, 7), (333, 5, 64), (1025, 6, 1024), (2500, 7, 300)])
-def test_upgma_fused_single_workgroup_bit_exact(hic, orc, monkeypatch, n, seed, dcap):
-    """HICMI_NNCHAIN_FUSED1=1: the narrow epochs on k_nn_epoch_mwc<1> - one workgroup running the column-sliced kernel's
-    fused update + scan pass (the A/B partner of k_nn_epoch_nc)."""
-    monkeypatch.setenv("HICMI_NNCHAIN_FUSED1", "1")
     monkeypatch.setenv("HICMI_NNCHAIN_DCAP", str(dcap))
     rng = np.random.default_rng(seed)
     c = rng.random((n, n)) + 0.01
@@ -784,16 +753,24 @@ def test_cli_drop_in(hic, tmp_path):
 
 
 @pytest.mark.parametrize("env", [{"HICMI_P2_HOST_INSERT": "1"}, {"HICMI_P2_INS_MAXC": "1"}, {"HICMI_P2_WINDOW_DIRECT": "1"},
-                                 {"HICMI_PART2_LOCKSTEP": "0"}],
+                                 {"HICMI_PART2_LOCKSTEP": "0"}, {"HICMI_P2_WINDOW_VALU": "1"}, {"HICMI_P2_INSB_SPLIT": "1"},
+                                 {"HICMI_PART2_WORKERS": "1"}, {"HICMI_PART2_WORKERS": "3"}, {"HICMI_REPARSE_FOR_PART2": "1"},
+                                 {"HICMI_NNCHAIN_NO_COMPACT": "1"}, {"HICMI_NNCHAIN_W1": "0"},
+                                 {"HICMI_NNCHAIN_W1_MAXS": "3", "HICMI_NNCHAIN_W1_COLS": "64"}],
                          ids=["host-decides-every-step", "device-with-host-steps-on-ties", "per-candidate-window-kernels",
-                              "one-queue-per-chromosome"])
+                              "one-queue-per-chromosome", "window-tables-on-the-vector-alu", "base-term-as-its-own-launch",
+                              "one-part2-worker", "three-part2-workers", "matrix-parsed-again-for-part2",
+                              "nn-chain-without-compaction", "nn-chain-on-the-1024-lane-kernels", "nn-chain-three-narrow-slices"])
 def test_insertion_paths_agree(hic, tmp_path, env):
     """orderRemainderScaffolds runs with the per-step decisions on the device (k_part2_insert.hip).  The same
     golden files must come out when the host decides every step, and when the device's short list is capped
     at one candidate so that every tie falls back to a host step in the middle of the queue; likewise with the
     windows scored candidate by candidate instead of from placement tables (k_part2_window.hip) and with one
     insertion queue per chromosome instead of the lock step (the switches are read once per process, hence the
-    subprocess)."""
+    subprocess).  The same harness covers every other switch that selects product code and has no test of its own:
+    the window tables' outside term on the vector ALU instead of the matrix cores, the BASE term as its own launch, the
+    number of Part 2 worker threads, the text matrix parsed again for Part 2 like the reference, the nn-chain without
+    compaction, on the 1,024-lane kernels of rounds 1-2, and on three 64-column slices of the one-wave kernel."""
     import subprocess
     import sys
     from hic_genome_assembler_amd import synth
