@@ -832,7 +832,7 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
             if (!again.empty()) {
                 if (c->row_list_cap < n) {
                     free_dev(c->d_row_list); c->d_row_list = nullptr;
-                    HIPCHK(hipMalloc((void**)&c->d_row_list, sizeof(int32_t) * (size_t)n));
+                    HIPCHK(hipMalloc((void**)&c->d_row_list, sizeof(int32_t) * 2 * (size_t)n));     // the list + one flag per listed row
                     c->row_list_cap = n;
                 }
                 int rc_up = upload(c, c->d_row_list, again.data(), sizeof(int32_t) * again.size());
@@ -853,7 +853,7 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
                 } else {
                     Timed t(c, F_RANK_TIED, (2.0 + 2.0) * (double)n * (double)n * part);
                     launch_rank_rows_tied(c->dR, c->d_tie_bits, c->ld_bits, c->d_order, c->d_order + n, (int)n, c->d_row_list,
-                                          (int)again.size(), c->dRank, ldr, c->stream);
+                                          (int)again.size(), c->dRank, ldr, c->stream, c->d_row_list + n);
                 }
             }
             HIPCHK(hipGetLastError());

@@ -196,7 +196,7 @@ void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const 
 // Rank rows of rows that hold equal keys, from the storage-label sort + its tie bits (k_sort_tied.hip).
 void launch_rank_rows_tied(const uint16_t* R_storage, const uint16_t* tie_bits, int64_t ld_bits, const int32_t* order,
                            const int32_t* inv, int n, const int32_t* row_list, int n_list, uint16_t* rank, int64_t ldr,
-                           hipStream_t s);
+                           hipStream_t s, int32_t* done = nullptr);     // done: n_list ints of scratch (rows finished by the short-run kernel)
 // rank[a][b] = rank_storage[order[a]][order[b]] (rows without equal keys; see k_sort.hip)
 void launch_rank_relabel(const uint16_t* rank_storage, uint16_t* rank, int64_t ldr, int n, const int32_t* order, int row_first,
                          int row_stride, hipStream_t s);

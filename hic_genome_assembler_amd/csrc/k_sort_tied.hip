@@ -89,7 +89,7 @@ template <int E>
 __global__ __launch_bounds__(CK_T) void k_rank_rows_tied(
     const uint16_t* __restrict__ R_storage, const uint16_t* __restrict__ tie_bits, int64_t ld_bits,
     const int32_t* __restrict__ order, const int32_t* __restrict__ inv, int n, int P, const int32_t* __restrict__ row_list,
-    int n_list, uint16_t* __restrict__ rank, int64_t ldr)
+    int n_list, uint16_t* __restrict__ rank, int64_t ldr, const int32_t* __restrict__ done)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* xk = reinterpret_cast<uint32_t*>(smem);
@@ -99,6 +99,7 @@ __global__ __launch_bounds__(CK_T) void k_rank_rows_tied(
     uint32_t K[E];
 
     for (int it = blockIdx.x; it < n_list; it += gridDim.x) {
+        if (done && done[it]) continue;                     // (finished by k_rank_rows_short_runs)
         int tid = tid0;
         asm volatile("" : "+v"(tid));                       // (see k_sort_rows_rb: keeps lane addresses out of the row loop)
         const int a = row_list[it];                         // row in leaf numbering
@@ -187,10 +188,154 @@ __global__ __launch_bounds__(CK_T) void k_rank_rows_tied(
     }
 }
 
+// ---- rows whose runs of equal keys are all SHORT --------------------------------------------------------------------
+// fp32-valued contacts give every row a few collisions - pairs, now and then a triple - and the full network above then
+// does all log^2 stages on a sequence that is sorted already except inside those runs (64,000 bins: 73 ms per map).  A run
+// of at most 8 elements lies inside an aligned block of 16 or inside a block shifted by 8, and sorting a block only
+// permutes the elements inside its runs (the run number is the key's high half, and the runs are in order): two rounds
+// of 16-element bitonic sorts in registers - 20 compare-exchange layers and two 8-key hand-overs between neighbouring
+// lanes instead of 136 layers, about 50 of them through LDS.  Rows with a longer run (sparse maps: the run of zeros) are
+// left to k_rank_rows_tied, which skips the rows marked done here.
+static constexpr int CKS_MAXRUN = 8;
+
+template <int E>
+__device__ __forceinline__ void cks_sort_blocks16(uint32_t (&A)[E])
+{
+#pragma unroll
+    for (int k = 2; k <= 16; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+#pragma unroll
+            for (int q = 0; q < E; q++)
+                if ((q & j) == 0) {
+                    const uint32_t lo = A[q] < A[q | j] ? A[q] : A[q | j];
+                    const uint32_t hi = A[q] < A[q | j] ? A[q | j] : A[q];
+                    const bool asc = k == 16 || (q & k) == 0;         // the last merge: every block ascending
+                    A[q] = asc ? lo : hi;
+                    A[q | j] = asc ? hi : lo;
+                }
+        }
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(CK_T) void k_rank_rows_short_runs(
+    const uint16_t* __restrict__ R_storage, const uint16_t* __restrict__ tie_bits, int64_t ld_bits,
+    const int32_t* __restrict__ order, const int32_t* __restrict__ inv, int n, int P, const int32_t* __restrict__ row_list,
+    int n_list, uint16_t* __restrict__ rank, int64_t ldr, int32_t* __restrict__ done)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* halo = reinterpret_cast<uint32_t*>(smem);    // 8 keys per lane (32 KB), before the rank image uses the space
+    uint16_t* img = reinterpret_cast<uint16_t*>(smem);
+    __shared__ uint32_t s_wmax[CK_T / 64];
+    __shared__ int s_maxrun;
+    const int tid0 = threadIdx.x;
+    uint32_t K[E];
+
+    for (int it = blockIdx.x; it < n_list; it += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int a = row_list[it];
+        const int srow = order[a];
+        const uint16_t* __restrict__ rs = R_storage + (int64_t)srow * ldr;
+        const uint16_t* __restrict__ bits = tie_bits + (int64_t)srow * ld_bits;
+        const int e0 = E * tid;
+        const bool live = e0 < P;
+        if (tid == 0) s_maxrun = 0;
+        // ---- run starts: prefix maximum of (bit ? 0 : e) over ascending e (as in k_rank_rows_tied)
+        uint32_t run_local = 0;
+#pragma unroll
+        for (int g = 0; g < E / 16; g++) {
+            const int eg = e0 + 16 * g;
+            const uint32_t w = (live && eg < n) ? bits[eg / 16] : 0u;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int e = eg + q;
+                const bool same = (w >> q) & 1u;
+                if (!same && e < n) run_local = (uint32_t)e;
+                K[16 * g + q] = same ? 0xffffffffu : (uint32_t)e;
+            }
+        }
+        uint32_t incl = run_local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+            if ((tid & 63) >= d && o > incl) incl = o;
+        }
+        if ((tid & 63) == 63) s_wmax[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t before = (uint32_t)__shfl_up((int)incl, 1, 64);
+        if ((tid & 63) == 0) before = 0;
+        for (int w = 0; w < (tid >> 6); w++) before = s_wmax[w] > before ? s_wmax[w] : before;
+        // ---- composite keys, and the longest run of the row
+        uint32_t cur = before;
+        int longest = 0;
+#pragma unroll
+        for (int q = 0; q < E; q++) {
+            const int e = e0 + q;
+            if (K[q] != 0xffffffffu) cur = K[q];
+            uint32_t key = 0xffffffffu;
+            if (live && e < n) {
+                key = (cur << 16) | (uint32_t)inv[rs[n - 1 - e]];
+                const int len = e - (int)cur + 1;
+                longest = len > longest ? len : longest;
+            }
+            K[q] = key;
+        }
+        if (longest > CKS_MAXRUN) atomicMax(&s_maxrun, longest);
+        __syncthreads();
+        if (s_maxrun > CKS_MAXRUN) { __syncthreads(); continue; }      // a long run: the full network's row (uniform)
+        // ---- round 1: aligned blocks of 16
+        cks_sort_blocks16<E>(K);
+        // ---- round 2: blocks shifted by 8 - the lane's elements 8 .. E-1 and the first 8 of the next lane
+        uint32_t H[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) halo[q * CK_T + tid] = K[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; q++) H[q] = tid + 1 < CK_T ? halo[q * CK_T + tid + 1] : 0xffffffffu;
+        __syncthreads();
+        {
+            uint32_t L[E];
+#pragma unroll
+            for (int q = 0; q < E - 8; q++) L[q] = K[q + 8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) L[E - 8 + q] = H[q];
+            cks_sort_blocks16<E>(L);
+#pragma unroll
+            for (int q = 0; q < E - 8; q++) K[q + 8] = L[q];
+#pragma unroll
+            for (int q = 0; q < 8; q++) H[q] = L[E - 8 + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) halo[q * CK_T + tid] = H[q];       // the next lane's first 8, sorted with my last 8
+        __syncthreads();
+        if (tid > 0) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) K[q] = halo[q * CK_T + tid - 1];
+        }
+        __syncthreads();
+        // ---- rank image and the row (as in k_rank_rows_tied)
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < E; q++) {
+                const int e = e0 + q;
+                if (e < n) img[K[q] & 0xffffu] = (uint16_t)(n - 1 - e);
+            }
+        }
+        __syncthreads();
+        uint4* __restrict__ o = reinterpret_cast<uint4*>(rank + (int64_t)a * ldr);
+        const int groups = (n + 7) / 8;
+        for (int g = tid; g < groups; g += CK_T) o[g] = reinterpret_cast<const uint4*>(img)[g];
+        if (tid == 0) done[it] = 1;
+        __syncthreads();
+    }
+}
+
 template <int E>
 static void launch_tied(const uint16_t* R_storage, const uint16_t* tie_bits, int64_t ld_bits, const int32_t* order,
                         const int32_t* inv, int n, int P, const int32_t* row_list, int n_list, uint16_t* rank, int64_t ldr,
-                        hipStream_t s)
+                        int32_t* done, hipStream_t s)
 {
     size_t lds = (size_t)CK_CHUNK * CK_T * sizeof(uint32_t);
     const size_t image = ((size_t)((n + 7) & ~7) * sizeof(uint16_t) + 15) & ~(size_t)15;
@@ -198,23 +343,31 @@ static void launch_tied(const uint16_t* R_storage, const uint16_t* tie_bits, int
     static size_t have = 0;
     if (lds > have) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_rows_tied<E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_rows_short_runs<E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         have = lds;
     }
     const int grid = n_list < 1024 ? n_list : 1024;
+    // rows whose runs are short are finished by the two-round block sort; the full network takes what is left
+    static const bool full_only = getenv("HICMI_TIED_FULL") != nullptr;        // A/B: every row through the full network
+    if (done && !full_only) {
+        hipMemsetAsync(done, 0, sizeof(int32_t) * (size_t)n_list, s);
+        hipLaunchKernelGGL(k_rank_rows_short_runs<E>, dim3(grid), dim3(CK_T), lds, s, R_storage, tie_bits, ld_bits, order, inv, n, P,
+                           row_list, n_list, rank, ldr, done);
+    }
     hipLaunchKernelGGL(k_rank_rows_tied<E>, dim3(grid), dim3(CK_T), lds, s, R_storage, tie_bits, ld_bits, order, inv, n, P,
-                       row_list, n_list, rank, ldr);
+                       row_list, n_list, rank, ldr, (done && !full_only) ? done : nullptr);
 }
 
 void launch_rank_rows_tied(const uint16_t* R_storage, const uint16_t* tie_bits, int64_t ld_bits, const int32_t* order,
                            const int32_t* inv, int n, const int32_t* row_list, int n_list, uint16_t* rank, int64_t ldr,
-                           hipStream_t s)
+                           hipStream_t s, int32_t* done)
 {
     if (n_list < 1) return;
     int P = sort_padded_size(n);
     if (P < 16) P = 16;
-    if (P <= 16 * CK_T) launch_tied<16>(R_storage, tie_bits, ld_bits, order, inv, n, P, row_list, n_list, rank, ldr, s);
-    else if (P <= 32 * CK_T) launch_tied<32>(R_storage, tie_bits, ld_bits, order, inv, n, P, row_list, n_list, rank, ldr, s);
-    else launch_tied<64>(R_storage, tie_bits, ld_bits, order, inv, n, P, row_list, n_list, rank, ldr, s);
+    if (P <= 16 * CK_T) launch_tied<16>(R_storage, tie_bits, ld_bits, order, inv, n, P, row_list, n_list, rank, ldr, done, s);
+    else if (P <= 32 * CK_T) launch_tied<32>(R_storage, tie_bits, ld_bits, order, inv, n, P, row_list, n_list, rank, ldr, done, s);
+    else launch_tied<64>(R_storage, tie_bits, ld_bits, order, inv, n, P, row_list, n_list, rank, ldr, done, s);
 }
 
 }  // namespace hicmi

@@ -25,6 +25,7 @@ device-resident matrix by plotContactMaps.py (exact percentiles, figure-resoluti
 from __future__ import annotations
 
 import os
+import sys
 import time
 
 import numpy as np
@@ -590,6 +591,11 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
     writer = _FileWriter(overlap_files)
     adjMat.finish_files = writer.finish
     adjMat.release_files = writer.release
+    marks = [("start", time.perf_counter())] if os.environ.get("HICMI_STEP_PROFILE") else None
+
+    def mark(name):
+        if marks is not None:
+            marks.append((name, time.perf_counter()))
     with paused_gc():
         t0 = time.time()
         if shard is not None:
@@ -600,6 +606,7 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
         adjMat, binList = removeRows(adjMat, binList, zeroRows=True, biasVals=False)
         adjMat.kept_bins = list(binList)                  # rows of the device matrix, in .bed order
         adjMat = convertMatrix(adjMat, binList, distance=True, similarity=False)
+        mark("row sums")
         # host work that does not depend on the tree runs while the chain does (a single ~100 ms native call): the labels,
         # the size table and the scaffold -> bins table of the assessment
         prep = {}
@@ -609,6 +616,7 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
             prep["sizes"] = readSizeFileToDict(hicProScaffSizeFile)
             prep["scaffolds"] = _scaffold_bins((b.ID, b.chrom) for b in bl)
         dendrogram = averageClusterNodes(adjMat, lambda: prep["labels"], noPlot=True, meanwhile=meanwhile)
+        mark("UPGMA + leaf order")
         writer.submit(dendrogramLeafOrder_toFile, dendrogram, dendrogramOrderFile)
         # the reference parses the file back (readDengrogramLeavesFromFile); the leaves are the same integers
         adjMat, binList = reorderMatrix(adjMat, binList, dendrogram['leaves'])
@@ -616,9 +624,12 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
         t0 = time.time()
         adjMat = convertMatrix(adjMat, binList, distance=False, similarity=True)
         argsorted_adjMat = rankOrderMatrix(adjMat)
+        mark("reorder + rank matrix")
         initial_cut_inds = pre_process_all_matrix_breakpoints(argsorted_adjMat, min_size=minSize,
                                                               min_frac=modularity, psig=psig)
+        mark("first-pass scans")
         cutIndices = filter_noisy_breakpoints(argsorted_adjMat, initial_cut_inds, psig=psig)
+        mark("filter scans")
         if modularity is not False and modularity > 0.0:
             # S2C:1148-1152: Louvain on log10(similarity + 1) of the bins after the last cut index (modularity.py:
             # seeded restatement of python-louvain; the cells come from the device in the current order)
@@ -641,6 +652,10 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
         adjMat.chromosome_groups = rankChromosomeGroups(chrGroups, fastaSizeDict)
         writer.submit(writeChromosomeGroupingsToFile, chrGroups, fastaSizeDict, chromosomeGroupFile, deferred=True)
         print("Total run-time to assign scaffolds to chromosomes = " + str(time.time() - t0))
+        mark("groups + assessment")
     if not overlap_files:
         writer.finish()
+    if marks is not None:
+        sys.stderr.write("[hicmi] part1 host timeline (ms): " + ", ".join(
+            "%s %.1f" % (b[0], (b[1] - a[1]) * 1e3) for a, b in zip(marks, marks[1:])) + "\n")
     return cutIndices

@@ -756,11 +756,13 @@ def test_cli_drop_in(hic, tmp_path):
                                  {"HICMI_PART2_LOCKSTEP": "0"}, {"HICMI_P2_WINDOW_VALU": "1"}, {"HICMI_P2_INSB_SPLIT": "1"},
                                  {"HICMI_PART2_WORKERS": "1"}, {"HICMI_PART2_WORKERS": "3"}, {"HICMI_REPARSE_FOR_PART2": "1"},
                                  {"HICMI_NNCHAIN_NO_COMPACT": "1"}, {"HICMI_NNCHAIN_W1": "0"},
-                                 {"HICMI_NNCHAIN_W1_MAXS": "3", "HICMI_NNCHAIN_W1_COLS": "64"}],
+                                 {"HICMI_NNCHAIN_W1_MAXS": "3", "HICMI_NNCHAIN_W1_COLS": "64"},
+                                 {"HICMI_TIED_FULL": "1", "HICMI_PRESORT_FROM": "100"}],
                          ids=["host-decides-every-step", "device-with-host-steps-on-ties", "per-candidate-window-kernels",
                               "one-queue-per-chromosome", "window-tables-on-the-vector-alu", "base-term-as-its-own-launch",
                               "one-part2-worker", "three-part2-workers", "matrix-parsed-again-for-part2",
-                              "nn-chain-without-compaction", "nn-chain-on-the-1024-lane-kernels", "nn-chain-three-narrow-slices"])
+                              "nn-chain-without-compaction", "nn-chain-on-the-1024-lane-kernels", "nn-chain-three-narrow-slices",
+                              "tied-rows-through-the-full-network"])
 def test_insertion_paths_agree(hic, tmp_path, env):
     """orderRemainderScaffolds runs with the per-step decisions on the device (k_part2_insert.hip).  The same
     golden files must come out when the host decides every step, and when the device's short list is capped
@@ -1117,6 +1119,43 @@ def test_rows_sorted_beside_the_chain_equal_rows_sorted_after_it(hic, monkeypatc
         assert state == 1
         # (two close contacts can round to the same similarity: ~n/1000 more rows than the planted ones may be flagged)
         assert len(tied) <= n_tied <= len(tied) + 3 + n // 400
+
+
+@pytest.mark.parametrize("n", [3000, 20000, 40000])        # 16 / 32 / 64 elements per lane
+def test_rank_rows_with_short_runs_of_equal_similarities(hic, monkeypatch, n):
+    """fp32-valued contacts give every row a few collisions; such rows are finished by k_rank_rows_short_runs (two rounds of
+    16-element block sorts: a run of at most 8 elements lies in an aligned block or in one shifted by 8), rows with a longer
+    run by the full network.  Planted here: runs of 2 ... 8 equal values at random sorted positions of many rows (hence at
+    every offset against the block, lane and wave boundaries), runs of 9 and 13 in a few rows, and rows that hold both.
+    The argsort rows must be numpy's stable argsort, reversed, of the very similarity row the library computes."""
+    monkeypatch.setenv("HICMI_PRESORT_FROM", "1000")
+    rng = np.random.default_rng(n)
+    c = rng.random((n, n), dtype=np.float32).astype(np.float64) + 0.01        # fp32-valued: a few natural collisions as well
+    c = np.triu(c) + np.triu(c, 1).T
+    rows = rng.choice(n, size=60, replace=False)
+    for t, r in enumerate(rows):
+        by_value = np.argsort(c[r], kind="stable")
+        lengths = [2 + (t % 7)] * 3                                            # short runs: 2 .. 8
+        if t % 10 == 3:
+            lengths += [9]
+        if t % 10 == 7:
+            lengths = [13] + lengths
+        for L in lengths:
+            p0 = int(rng.integers(0, n - L))
+            cols = by_value[p0:p0 + L]
+            c[r, cols] = c[r, cols[0]]
+            c[cols, r] = c[r, cols[0]]
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(c)
+        leaves, _z = ctx.upgma()
+        ctx.rank_matrix(leaves)
+        state, n_tied = ctx.presort_state()
+        assert state == 1 and n_tied >= len(rows)
+        where = {int(r): k for k, r in enumerate(leaves)}
+        check = [where[int(r)] for r in rows] + rng.integers(0, n, 30).tolist() + [0, n - 1]
+        for a in check:
+            sim = ctx.similarity_row(a)
+            assert np.array_equal(ctx.rank_rows(a, 1)[0].astype(np.int64), np.argsort(sim, kind="stable")[::-1]), a
 
 
 @pytest.mark.parametrize("n", [20000, 40000])              # 32 / 64 elements per lane in k_rank_rows_tied
