@@ -78,6 +78,8 @@ SIGNATURES = {
     "hicmi_p2_insert_all_multi": (ctypes.c_int, [c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hicmi_p2_scan_pass": (ctypes.c_int, [_vp, _vp, _vp, c_i64, c_i64, c_dbl, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl),
                                           ctypes.POINTER(ctypes.c_int32)]),
+    "hicmi_p2_scan_all": (ctypes.c_int, [_vp, _vp, _vp, c_i64, c_i64, c_dbl, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl),
+                          ctypes.POINTER(c_i64)]),
     "hicmi_timing_reset": (ctypes.c_int, [_vp]),
     "hicmi_timing_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "hicmi_timing_get": (ctypes.c_int, [_vp, ctypes.c_char_p, c_i64, _vp, _vp, _vp, c_i64, ctypes.POINTER(c_i64)]),
@@ -482,6 +484,18 @@ class Context:
                                             ctypes.byref(cf), ctypes.byref(imp)))
         self._arr_sig = None
         return a, b, bst.value, cf.value, bool(imp.value)
+
+    def p2_scan_all(self, ids, rev, k, total, best, cur_fast):
+        """scanOrdering's rounds until one brings no improvement; returns (ids, rev, best, cur_fast, rounds)."""
+        a = np.ascontiguousarray(ids, dtype=np.int32).copy()
+        b = np.ascontiguousarray(rev, dtype=np.uint8).copy()
+        bst = c_dbl(float(best))
+        cf = c_dbl(float("nan") if cur_fast is None else float(cur_fast))
+        rounds = c_i64()
+        _check(self._lib.hicmi_p2_scan_all(self._h, _ptr(a), _ptr(b), len(a), int(k), float(total), ctypes.byref(bst),
+                                           ctypes.byref(cf), ctypes.byref(rounds)))
+        self._arr_sig = None
+        return a, b, bst.value, cf.value, int(rounds.value)
 
     # ---- plot support
     def plot_percentiles(self, kind, order, q):

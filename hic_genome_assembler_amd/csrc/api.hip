@@ -1983,6 +1983,23 @@ int hicmi_p2_scan_pass(hicmi_ctx* c, int32_t* ids, uint8_t* rev, int64_t S, int6
     return HICMI_OK;
 }
 
+int hicmi_p2_scan_all(hicmi_ctx* c, int32_t* ids, uint8_t* rev, int64_t S, int64_t k, double total, double* best_io,
+                      double* cur_fast_io, int64_t* rounds_out)
+{
+    // scanOrdering's outer loop (OG:509-547) as ONE call: a chromosome's ~20 rounds are ~20 returns to the interpreter
+    // otherwise, each of which waits for the interpreter lock behind the other chromosomes' threads
+    if (!rounds_out) return fail(HICMI_EINVAL, "bad arguments");
+    *rounds_out = 0;
+    for (;;) {
+        int32_t improved = 0;
+        int rc = hicmi_p2_scan_pass(c, ids, rev, S, k, total, best_io, cur_fast_io, &improved);
+        if (rc) return rc;
+        ++*rounds_out;
+        if (!improved) return HICMI_OK;
+        if (*rounds_out > 100000) return fail(HICMI_ESTATE, "scanOrdering does not converge");
+    }
+}
+
 // ---- plot support (plotContactMaps.py:15-91) --------------------------------------------------------
 namespace {
 int plot_prepare(hicmi_ctx* c, int kind, const int32_t* order, int64_t n_sel, int32_t** d_order_out)

@@ -560,12 +560,18 @@ def scanOrdering(orderedScaffolds, scaffoldDict, orderDict, matrix: GenomeMatrix
         layout = adjMat.layout
         layout.tables(w)
         ids, rev = layout.describe(orderedScaffolds)
-        while True:
-            print("Working on round " + str(roundNumber + 1) + " of final step...")
-            ids, rev, bestCost, cur_fast, improved = adjMat.ctx.p2_scan_pass(ids, rev, w, total, bestCost, cur_fast)
-            roundNumber += 1
-            if not improved:
-                break
+        if hasattr(adjMat.ctx, "p2_scan_all"):
+            # the whole loop as one native call (the interpreter lock is free for the other chromosomes meanwhile)
+            ids, rev, bestCost, cur_fast, roundNumber = adjMat.ctx.p2_scan_all(ids, rev, w, total, bestCost, cur_fast)
+            for r in range(roundNumber):
+                print("Working on round " + str(r + 1) + " of final step...")
+        else:
+            while True:
+                print("Working on round " + str(roundNumber + 1) + " of final step...")
+                ids, rev, bestCost, cur_fast, improved = adjMat.ctx.p2_scan_pass(ids, rev, w, total, bestCost, cur_fast)
+                roundNumber += 1
+                if not improved:
+                    break
         orderedScaffolds, _nodes = reorderScaffList([layout.names[i] for i in ids], ["-" if r else "+" for r in rev],
                                                     scaffoldDict)
         print("Sliding window conversion after " + str(roundNumber) + " rounds")
@@ -614,12 +620,21 @@ def _startChromosome(chromGroup, matrix: GenomeMatrix, binList, nScaffolds=6, sc
         nScaffolds = 8
     if scanScaffolds > nScaffolds:
         scanScaffolds = nScaffolds
+    tm = [time.perf_counter()] if _PROFILE else None
     scaffoldList, scaffoldDict = initiateBinsAndScaffolds(chromGroup)
+    if tm: tm.append(time.perf_counter())
     matrix.chrom = ChromosomeLayout(matrix, scaffoldList, binList)      # one selection for the whole chromosome
+    if tm: tm.append(time.perf_counter())
     orderedScaffolds, scaffoldList = pullScaffolds([], scaffoldList, nScaffolds)
     adjMat, orderDict = giveNewAdjMat(matrix, orderedScaffolds, binList)
+    if tm: tm.append(time.perf_counter())
     bfOrder, bfOrient, _bfScore = bruteForceBestScore(orderedScaffolds, scaffoldDict, adjMat, orderDict)
+    if tm: tm.append(time.perf_counter())
     orderedScaffolds, _nodes = reorderScaffList(bfOrder, bfOrient, scaffoldDict)
+    if tm:
+        tm.append(time.perf_counter())
+        sys.stderr.write("[hicmi] part2 start of a %d-bin chromosome (ms): scaffolds %.2f, layout + selection %.2f, sub-matrix view %.2f, "
+                         "brute force %.2f, reorder %.2f\n" % ((len(chromGroup),) + tuple((b - a) * 1e3 for a, b in zip(tm, tm[1:]))))
     return {"ordered": orderedScaffolds, "rest": scaffoldList, "dict": scaffoldDict, "orderDict": orderDict,
             "nScaffolds": nScaffolds, "scanScaffolds": scanScaffolds}
 

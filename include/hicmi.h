@@ -253,11 +253,15 @@ int hicmi_p2_decide_insertion(hicmi_ctx *ctx, const int32_t *ids, const uint8_t 
  * in pull order, each entering in '+' orientation.  best_out = bestCost of the last insertion.
  * hicmi_p2_scan_pass = one round of scanOrdering (OG:513-541) over windows of k scaffolds, every
  * winner applied before the next window; ids/rev updated in place, *best_io / *cur_fast_io carried,
- * *improved_out = 1 if any window improved (the reference's `stop`). */
+ * *improved_out = 1 if any window improved (the reference's `stop`).
+ * hicmi_p2_scan_all = the whole `while True` loop of scanOrdering (OG:509-547): rounds until one brings no
+ * improvement, *rounds_out = how many ran ("Working on round i of final step..." is printed once per round by the caller). */
 int hicmi_p2_insert_all(hicmi_ctx *ctx, int32_t *ids, uint8_t *rev, int64_t S0, const int32_t *new_ids, int64_t n_new,
                         double *best_out);
 int hicmi_p2_scan_pass(hicmi_ctx *ctx, int32_t *ids, uint8_t *rev, int64_t S, int64_t k, double total, double *best_io,
                        double *cur_fast_io, int32_t *improved_out);
+int hicmi_p2_scan_all(hicmi_ctx *ctx, int32_t *ids, uint8_t *rev, int64_t S, int64_t k, double total, double *best_io,
+                      double *cur_fast_io, int64_t *rounds_out);
 /* hicmi_p2_insert_all for n_jobs chromosomes at once (the loop over chromosomes of OG:608-612 turned
  * inside out): job j uses context ctxs[j] - its own selection and layout, all contexts on one device - and
  * the arrays ids[j] / rev[j] / new_ids[j] with S0[j] / n_new[j] entries as above.  The chromosomes advance
