@@ -12,6 +12,7 @@
 #include <string>
 #include <unordered_map>
 #include <functional>
+#include <chrono>
 #include <vector>
 
 #include "../../include/hicmi.h"
@@ -778,6 +779,16 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
     if (!c->dC) return fail(HICMI_EINVAL, "no contact matrix set");
     HIPCHK(hipSetDevice(c->device));
     const int64_t n = c->n;
+    static const bool tprof = getenv("HICMI_STEP_PROFILE") != nullptr;
+    std::vector<std::chrono::steady_clock::time_point> tm;
+    auto tick = [&]() { if (tprof) tm.push_back(std::chrono::steady_clock::now()); };
+    auto report = [&]() {
+        if (!tprof || tm.size() < 2) return;
+        fprintf(stderr, "[hicmi] rank_matrix host timeline (ms):");
+        for (size_t i = 1; i < tm.size(); i++) fprintf(stderr, " %.2f", std::chrono::duration<double, std::milli>(tm[i] - tm[i - 1]).count());
+        fprintf(stderr, "\n");
+    };
+    tick();
     std::vector<uint8_t> seen((size_t)n, 0);
     for (int64_t i = 0; i < n; i++) {
         if (order[i] < 0 || order[i] >= n || seen[(size_t)order[i]]) return fail(HICMI_EINVAL, "order is not a permutation of 0..n-1");
@@ -793,7 +804,9 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
     // cost more than the 105 register-resident stages.  Kept as the second implementation the large-map tests compare with.
     const bool bitonic = getenv("HICMI_SORT_RADIX") == nullptr;
     if (c->presort_n != n) c->presort_used = 0;
+    tick();
     if (c->presort_n && c->stream2) HIPCHK(hipStreamSynchronize(c->stream2));   // (the buffers below are the pre-sort's too)
+    tick();
     rc = ensure_rank_buffers(c, n, ldr, bitonic);
     if (rc) return rc;
     {
@@ -806,9 +819,11 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
     if (c->presort_n == n && bitonic) {
         // rows sorted in storage labels while the nn-chain ran (start_presort): re-addressed by the leaf order; rows that
         // hold equal keys get the order inside their runs from k_rank_rows_tied
+        tick();
         std::vector<unsigned char> ties(16 + (size_t)n);
         int rc_dl = download(c, ties.data(), c->d_ties, ties.size());
         if (rc_dl) return rc_dl;
+        tick();
         unsigned n_tied = 0;
         memcpy(&n_tied, ties.data(), sizeof(n_tied));
         // HICMI_PRESORT_TIES=resort: the rows with equal keys go through the full 64-bit sort again (the first version of
@@ -857,7 +872,10 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
                 }
             }
             HIPCHK(hipGetLastError());
+            tick();
             HIPCHK(sync_stream(c));
+            tick();
+            report();
             c->have_rank = true;
             c->cached_start = -1;
             return HICMI_OK;

@@ -170,9 +170,8 @@ def readDengrogramLeavesFromFile(dendrogramFile):
 
 def reorderMatrix(matrix: DeviceMatrix, binList, newOrder):
     """S2C:157-163: the permutation is applied by the consuming kernel through an index vector."""
-    newOrder = [int(v) for v in newOrder]
-    base = matrix.order if matrix.order is not None else list(range(matrix.n))
-    matrix.order = [base[i] for i in newOrder]
+    newOrder = np.asarray(newOrder, dtype=np.int64).tolist()
+    matrix.order = newOrder if matrix.order is None else [matrix.order[i] for i in newOrder]
     return matrix, [binList[i] for i in newOrder]
 
 
@@ -617,13 +616,15 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
             prep["scaffolds"] = _scaffold_bins((b.ID, b.chrom) for b in bl)
         dendrogram = averageClusterNodes(adjMat, lambda: prep["labels"], noPlot=True, meanwhile=meanwhile)
         mark("UPGMA + leaf order")
-        writer.submit(dendrogramLeafOrder_toFile, dendrogram, dendrogramOrderFile)
         # the reference parses the file back (readDengrogramLeavesFromFile); the leaves are the same integers
         adjMat, binList = reorderMatrix(adjMat, binList, dendrogram['leaves'])
         print("Total run-time to cluster = " + str(time.time() - t0))
         t0 = time.time()
         adjMat = convertMatrix(adjMat, binList, distance=False, similarity=True)
         argsorted_adjMat = rankOrderMatrix(adjMat)
+        # the dendrogram file (16k formatted lines: ~5 ms of interpreter time) is handed to the writer thread only now: the
+        # two scan loops that follow are native calls that release the interpreter lock, the list work above is not
+        writer.submit(dendrogramLeafOrder_toFile, dendrogram, dendrogramOrderFile)
         mark("reorder + rank matrix")
         initial_cut_inds = pre_process_all_matrix_breakpoints(argsorted_adjMat, min_size=minSize,
                                                               min_frac=modularity, psig=psig)
