@@ -738,6 +738,10 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         if (dq[9])
             fprintf(stderr, "[hicmi] one-wave kernel: %llu exchanges, post + polling %.2f ms, %.2f polls of the slowest peer per exchange\n",
                     dq[9], dq[8] / 1e5, (double)dq[10] / (double)dq[9]);
+        if (dq[9])
+            fprintf(stderr, "[hicmi] stand-alone scans by cause: chain restart %llu, exact tie %llu, neighbour of the merged cluster %llu, "
+                            "new neighbour of the row scanned with the merge %llu, reached over cached steps %llu, other %llu\n",
+                    dq[12], dq[13], dq[14], dq[15], dq[16], dq[17]);
     }
     if (nn.state[5] == 2)
         return fail(HICMI_ESTATE, "nn-chain: a peer workgroup of the column-sliced kernel answered late, and so did the retry");

@@ -1614,6 +1614,8 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
     unsigned long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;   // PROF: walk, scan, exchange+after, merge book, issue, arrive, compute, reduce, drain, -
     const bool prof = PROF && wg == 0;
     unsigned long long npolls = 0;                           // PROF: polls of the slowest-answering peer, summed over the exchanges (per lane)
+    unsigned long long kinds[6] = {0, 0, 0, 0, 0, 0};        // PROF: stand-alone scans by cause
+    int last_R = -1, last_A = -1, last_my = -1, pushed_cached = 0;
 #define W1_STAMP(k) do { if (prof) { const unsigned long long t1_ = wall_clock64(); tp[k] += t1_ - t0; t0 = t1_; } } while (0)
 
     auto umeta = [&](int i) -> uint32_t { return (uint32_t)w1_uni((int)meta[i]); };       // uniform i
@@ -1724,12 +1726,17 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
                 else if ((int)(e & W1_NOIDX) == prev) act = 2;
                 else if (prev >= 0 && ((e >> 15) & 1u)) act = 1;             // an exact tie: the value decides
                 else if (++guard > 4 * n + 8) { stop_code = NN_STOP_GUARD; act = 3; why = 2; }
-                else { push((int)(e & W1_NOIDX)); c_hits++; }
+                else { push((int)(e & W1_NOIDX)); c_hits++; pushed_cached = 1; }
             }
             if (act != 1) break;
             // ---- a scan on its own: this slice of row x, then one exchange
             const int x = top, prev = (len > 1) ? second : -1;      // (uniform: the chain state lives in scalar registers)
             c_scans++; c_cols += (unsigned long long)(total_steps + 1 - step);
+            if (PROF) {
+                const uint32_t ex0 = umeta(x);
+                const int kind = len == 1 ? 0 : ((ex0 & W1_NOIDX) != W1_NOIDX && entry_valid(ex0) ? 1 : (x == last_R ? 2 : (x == last_A ? 3 : (pushed_cached ? 4 : 5))));
+                kinds[kind]++;
+            }
             const uint32_t ex = umeta(x);
             W1_STAMP(0);
             const double* __restrict__ rowx = W + (int64_t)x * ld;
@@ -1912,6 +1919,7 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
         }
         // ---- the merged cluster's neighbour is known; the fused scan of row a is decided like a scan on its own
         tl++; done_e++;
+        if (PROF) { last_R = R.i; last_A = a >= 0 ? A.i : -1; last_my = my; pushed_cached = 0; }
         if (lane == 0) {
             const bool known = R.i >= 0 && R.i < n;
             meta[my] = (known ? (uint32_t)R.i | ((uint32_t)(R.t ? 1 : 0) << 15) : W1_NOIDX) | ((uint32_t)tl << 16) | ((uint32_t)tl << 24);
@@ -1967,6 +1975,7 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
             w.prof[4] += tp[4] + tp[5] + tp[6] + tp[7] + tp[8];
             w.prof[2] += tp[9];                                   // "pick" = post + polling + reductions + what follows the exchange
             p2[8] += tp[9]; p2[9] += (unsigned long long)(xseq - xseq0); p2[10] += npolls_max;
+            for (int q = 0; q < 6; q++) p2[12 + q] += kinds[q];
         }
     }
 #undef W1_STAMP
