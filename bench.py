@@ -414,6 +414,8 @@ def main():
     ap.add_argument("--kernel-times", choices=["part1", "all"], default="part1",
                     help="which kernel families get HIP-event timing inside the timed region")
     args = ap.parse_args()
+    if os.environ.get("HICMI_SWITCH_INTERVAL"):
+        sys.setswitchinterval(float(os.environ["HICMI_SWITCH_INTERVAL"]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
