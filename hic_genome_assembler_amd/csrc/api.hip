@@ -83,6 +83,7 @@ struct hicmi_ctx {
     unsigned char* d_ties = nullptr; int64_t ties_cap = 0;   // [count of flagged rows, 16 bytes][one flag per storage row]
     uint16_t* d_tie_bits = nullptr; int64_t tie_bits_rows = 0, ld_bits = 0;   // per storage row: "same key as the element before"
     int32_t* d_row_list = nullptr; int64_t row_list_cap = 0;
+    int64_t scan_first_batch = 0, scan_last_improved = 0;   // hicmi_p2_scan_all: the first batch size of the next round
     int64_t presort_tied_rows = 0;                        // ... and how many rows it re-sorted because they hold equal keys
     int presort_used = 0;                                 // last hicmi_rank_matrix: 0 sorted itself, 1 relabelled the pre-sort, 2 pre-sort discarded (ties)
     int64_t presort_n = 0;                                // > 0: dRankS holds the rows of the current n x n matrix
@@ -1973,7 +1974,11 @@ int hicmi_p2_scan_pass(hicmi_ctx* c, int32_t* ids, uint8_t* rev, int64_t S, int6
     const int64_t last = S - k;
     std::vector<double> delta;
     int64_t first = 0;
-    int64_t batch = 8;                                   // grows while no window improves
+    // windows scored per launch pair: 8, doubling while no window improves (an improvement throws the rest of the batch
+    // away); a round that follows a round with at most one improvement starts at 32 (hicmi_p2_scan_all: the late rounds
+    // of a chromosome change little, and a batch costs a launch pair + a synchronisation whatever its size)
+    int64_t batch = c->scan_first_batch > 0 ? c->scan_first_batch : 8;
+    int64_t n_improved = 0;
     while (first <= last) {
         const int64_t count = std::min<int64_t>(batch, last - first + 1);
         delta.resize((size_t)(count * n_cand));
@@ -1998,10 +2003,12 @@ int hicmi_p2_scan_pass(hicmi_ctx* c, int32_t* ids, uint8_t* rev, int64_t S, int6
             if (rc) return rc;
             first = f + 1;
             applied = true;
+            n_improved++;
             batch = 8;
         }
         if (!applied) { first += count; batch = std::min<int64_t>(batch * 2, 32); }
     }
+    c->scan_last_improved = n_improved;
     return HICMI_OK;
 }
 
@@ -2012,9 +2019,12 @@ int hicmi_p2_scan_all(hicmi_ctx* c, int32_t* ids, uint8_t* rev, int64_t S, int64
     // otherwise, each of which waits for the interpreter lock behind the other chromosomes' threads
     if (!rounds_out) return fail(HICMI_EINVAL, "bad arguments");
     *rounds_out = 0;
+    c->scan_first_batch = 0;
     for (;;) {
         int32_t improved = 0;
         int rc = hicmi_p2_scan_pass(c, ids, rev, S, k, total, best_io, cur_fast_io, &improved);
+        c->scan_first_batch = (rc == 0 && c->scan_last_improved <= 1) ? 32 : 0;
+        if (rc || !improved) { c->scan_first_batch = 0; }
         if (rc) return rc;
         ++*rounds_out;
         if (!improved) return HICMI_OK;

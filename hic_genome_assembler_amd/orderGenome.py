@@ -740,11 +740,16 @@ def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds
             marks.append(time.perf_counter())
 
             def finish(i):
+                tf = time.perf_counter()
                 st = states[i]
                 if i not in inserted:                                           # e.g. nothing left to add (OG:475-493)
                     inserted[i] = orderRemainderScaffolds(st["ordered"], st["rest"], st["orderDict"], lanes[i], binList)
                 ordered, best = inserted[i]
-                return i, _finishChromosome(st, ordered, best, lanes[i], binList)
+                res = _finishChromosome(st, ordered, best, lanes[i], binList)
+                if _PROFILE:
+                    sys.stderr.write("[hicmi] part2 scan of chromosome %d (%d bins): start +%.1f ms, %.1f ms\n"
+                                     % (i + 1, len(chromList[i]), (tf - marks[2]) * 1e3, (time.perf_counter() - tf) * 1e3))
+                return i, res
             done = dict(pool.map(finish, todo))
         marks.append(time.perf_counter())
         if _PROFILE:
