@@ -577,6 +577,8 @@ def scanOrdering(orderedScaffolds, scaffoldDict, orderDict, matrix: GenomeMatrix
                                                     scaffoldDict)
         print("Sliding window conversion after " + str(roundNumber) + " rounds")
         print("Best cost at the end of the final step = " + str(bestCost))
+        if _PROFILE:
+            sys.stderr.write("[hicmi] part2 scan: %d scaffolds, %d rounds\n" % (len(ids), roundNumber))
         return orderedScaffolds, bestCost
     while True:
         improved = False
