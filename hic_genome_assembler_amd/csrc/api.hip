@@ -1494,7 +1494,7 @@ int window_batch(hicmi_ctx* c, int64_t first0, int64_t count, int64_t k, double*
             launch_p2_window_batch(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, (int)k, c->d_wb, (int)count, max_m, c->d_orders,
                                    c->d_orients, (int)c->n_orders, (int)c->n_orients, c->d_H, c->d_G, c->d_delta, c->stream);
         else
-            launch_p2_window_tables(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, (int)k, c->d_wb, (int)count, max_m,
+            launch_p2_window_tables(c->dM2, c->ld2, c->d_pos2sel, (int)c->n_arr, (int)k, c->d_wb, wb.data(), (int)count, max_m,
                                     c->d_orders, c->d_orients, (int)c->n_orders, (int)c->n_orients, c->d_H, c->d_G, c->d_delta,
                                     c->stream);
     }

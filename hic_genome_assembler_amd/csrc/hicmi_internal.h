@@ -247,7 +247,7 @@ void launch_p2_window_batch(const double* M2, int64_t ld2, const int32_t* pos2se
 // per candidate); tables = n_win * window_table_doubles(k) doubles of scratch
 int64_t window_table_doubles(int k);
 void launch_p2_window_tables(const double* M2, int64_t ld2, const int32_t* pos2sel, int n, int k,
-                             const WindowBatchEntry* wb, int n_win, int max_m, const int8_t* orders, const uint8_t* orients,
+                             const WindowBatchEntry* wb, const WindowBatchEntry* h_wb, int n_win, int max_m, const int8_t* orders, const uint8_t* orients,
                              int n_ord, int n_ori, const double* H, double* tables, double* delta_all, hipStream_t s);
 
 // Lock-step insertion (k_part2_insert.hip): orderRemainderScaffolds for several chromosomes at once, every

@@ -28,13 +28,32 @@ __device__ __forceinline__ double wave_sum_w(double v)
     return v;
 }
 
-// per-window table layout (doubles): [Q: WT_SLICES x (k*2 << k)][P: k*k*4 << k][C: 8].  Q is accumulated in
-// WT_SLICES slices of the outside positions by separate workgroups (5 x 32 workgroups per batch would leave
-// most of the chip idle) and the slices are added, in order, when a candidate looks an entry up.
-static constexpr int WT_SLICES = 8;
+// per-window table layout (doubles): [Q: WT_SLICES x (k*2 << k)][P: k*k*4 << k][C: 8].  The Q entries of window
+// scaffold j are accumulated as nrg x nq partial tables by separate workgroups - groups of 16-row tiles of the scaffold
+// times slices of the outside positions, as many as bring a workgroup near WT_UNIT matrix instructions per wave
+// (wt_split: a 300-bin scaffold in a 400-bin window is ~40x the work of a 12-bin one in a 90-bin window, and one
+// workgroup per (window, scaffold, slice) left the launch waiting for the few heavy ones) - and k_win_pairs' diagonal
+// workgroups add the partial tables, in order, into slice 0 before the candidates look entries up.
+static constexpr int WT_SLICES = 64;
+static constexpr int WT_UNIT = 160;
 __host__ __device__ inline int64_t wt_q_size(int k) { return ((int64_t)k * 2) << k; }
 __host__ __device__ inline int64_t wt_p_size(int k) { return ((int64_t)k * k * 4) << k; }
 int64_t window_table_doubles(int k) { return WT_SLICES * wt_q_size(k) + wt_p_size(k) + 8; }
+
+// partial tables of a scaffold of Lj bins in a window of m bins with n_out positions outside: nrg groups of row tiles
+// (group g takes the tiles g, g + nrg, ...) x nq column slices; the same on the host (grid size) and in every kernel
+__host__ __device__ inline void wt_split(int Lj, int m, int n_out, int& nrg, int& nq)
+{
+    const int nr = Lj > 0 ? (Lj + 15) >> 4 : 1, tiles_w = ((((m + 15) >> 4) + 3) >> 2);
+    const int64_t work = (int64_t)nr * tiles_w * ((n_out + 3) >> 2);     // matrix instructions per wave
+    int64_t units = (work + WT_UNIT - 1) / WT_UNIT;
+    units = units < 1 ? 1 : (units > WT_SLICES ? WT_SLICES : units);
+    nrg = nr < (int)units ? nr : (int)units;
+    nq = (int)units / nrg;
+    const int by_cols = n_out >= 64 ? n_out / 32 : 1;
+    nq = nq > by_cols ? by_cols : nq;
+    nq = nq < 1 ? 1 : nq;
+}
 
 static constexpr int WT_ACC = 8;                        // table entries a wave accumulates per pass over the data
 
@@ -55,6 +74,9 @@ __global__ __launch_bounds__(256) void k_win_outside(const double* __restrict__ 
     const WindowBatchEntry& we = wb[blockIdx.y];
     const int j = blockIdx.x, p0 = we.p0, m = we.m;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int nrg, nq;
+    wt_split(we.w.len[j], m, n - m, nrg, nq);
+    if ((int)blockIdx.z >= nrg * nq) return;                // (the whole workgroup, before any barrier)
     if (tid < k) s_len[tid] = we.w.len[tid];
     const double hn = H[n - 1];
     if (H_IN_LDS) {
@@ -70,7 +92,8 @@ __global__ __launch_bounds__(256) void k_win_outside(const double* __restrict__ 
     }
     __syncthreads();
     const int Lj = s_len[j], startj = we.w.start[j], n_out = n - m;
-    const int q_lo = (int)(((int64_t)blockIdx.z * n_out) / WT_SLICES), q_hi = (int)(((int64_t)(blockIdx.z + 1) * n_out) / WT_SLICES);
+    const int rt = blockIdx.z % nrg, qs = blockIdx.z / nrg;
+    const int q_lo = (int)(((int64_t)qs * n_out) / nq), q_hi = (int)(((int64_t)(qs + 1) * n_out) / nq);
     double* __restrict__ Q = tables + (int64_t)blockIdx.y * table_stride + blockIdx.z * wt_q_size(k) + (((int64_t)j * 2) << k);
     const int n_entries = 2 << (k - 1);                     // (orientation, set of the other k-1 scaffolds)
     for (int e0 = wave * WT_ACC; e0 < n_entries; e0 += 4 * WT_ACC) {
@@ -83,7 +106,7 @@ __global__ __launch_bounds__(256) void k_win_outside(const double* __restrict__ 
             off[u] = p0 + s_glen[spread_bit(e & ((1 << (k - 1)) - 1), j)];
             acc[u] = 0.0;
         }
-        for (int i = 0; i < Lj; i++) {
+        for (int i = rt * 16; i < Lj; i = (i & 15) == 15 ? i + 1 + (nrg - 1) * 16 : i + 1) {   // the row tiles rt, rt + nrg, ...
             const double* __restrict__ row = M2 + (int64_t)(startj + i) * ld2;
 #pragma unroll 2
             for (int qq = q_lo + lane; qq < q_hi; qq += 64) {
@@ -119,10 +142,12 @@ __global__ __launch_bounds__(256) void k_win_outside(const double* __restrict__ 
 // a time (coalesced along q), wave w accumulates the slot tiles w, w + 4, ...; fp64 throughout.  Every entry is a
 // different summation order than the vector-ALU kernel's: neither reaches an output (winners are re-scored literally).
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
-static constexpr int WM_QC = 64;                          // outside positions staged per trip
+static constexpr int WM_QC = 128;                         // outside positions staged per trip (256 threads: 16 * WM_QC / 256 rows each)
 static constexpr int WM_MAX_TILES = 8;                    // slot tiles per wave: windows up to 4 * 8 * 16 = 512 bins
 
-template <bool H_IN_LDS>
+// TILES: slot tiles per wave (2, 4 or 8 by the widest window of the batch - the accumulators are most of the kernel's
+// registers, and with 2 a CU holds five workgroups instead of three)
+template <bool H_IN_LDS, int TILES>
 __global__ __launch_bounds__(256) void k_win_outside_mfma(const double* __restrict__ M2, int64_t ld2,
                                                           const int32_t* __restrict__ pos2sel, int n, int k,
                                                           const WindowBatchEntry* __restrict__ wb, const double* H,
@@ -130,15 +155,19 @@ __global__ __launch_bounds__(256) void k_win_outside_mfma(const double* __restri
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
     double* As = reinterpret_cast<double*>(smem_w);                          // [16][WM_QC + 1]
-    double* Gt = As + 16 * (WM_QC + 1);                                       // [16][m_pad_max]
+    double* Gt = As;                                                          // [16][m_pad_max], after the last fragment is read
+    const int as_doubles = 16 * (WM_QC + 1) > 16 * m_pad_max ? 16 * (WM_QC + 1) : 16 * m_pad_max;
     __shared__ int s_len[8], s_glen[256], s_pos[WM_QC], s_col[WM_QC];
     const WindowBatchEntry& we = wb[blockIdx.y];
     const int j = blockIdx.x, p0 = we.p0, m = we.m;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int nrg, nq;
+    wt_split(we.w.len[j], m, n - m, nrg, nq);
+    if ((int)blockIdx.z >= nrg * nq) return;                // (the whole workgroup, before any barrier)
     if (tid < k) s_len[tid] = we.w.len[tid];
     const double hn = H[n - 1];
     if (H_IN_LDS) {
-        double* hl = Gt + 16 * m_pad_max;
+        double* hl = As + as_doubles;
         for (int i = tid; i < n; i += 256) hl[i] = H[i];
         H = hl;
     }
@@ -150,7 +179,8 @@ __global__ __launch_bounds__(256) void k_win_outside_mfma(const double* __restri
     }
     __syncthreads();
     const int Lj = s_len[j], startj = we.w.start[j], n_out = n - m;
-    const int q_lo = (int)(((int64_t)blockIdx.z * n_out) / WT_SLICES), q_hi = (int)(((int64_t)(blockIdx.z + 1) * n_out) / WT_SLICES);
+    const int rt = blockIdx.z % nrg, qs = blockIdx.z / nrg;
+    const int q_lo = (int)(((int64_t)qs * n_out) / nq), q_hi = (int)(((int64_t)(qs + 1) * n_out) / nq);
     double* __restrict__ Q = tables + (int64_t)blockIdx.y * table_stride + blockIdx.z * wt_q_size(k) + (((int64_t)j * 2) << k);
     const int n_entries = 2 << (k - 1);                     // (orientation, set of the other k-1 scaffolds): <= 256
     const int m_pad = (m + 15) & ~15, n_tiles = m_pad >> 4;
@@ -158,37 +188,49 @@ __global__ __launch_bounds__(256) void k_win_outside_mfma(const double* __restri
     const int e_rev = tid < n_entries ? tid >> (k - 1) : 0;
     const int e_off = tid < n_entries ? s_glen[spread_bit(tid & ((1 << (k - 1)) - 1), j)] : 0;
     double qacc = 0.0;
-    for (int r0 = 0; r0 < Lj; r0 += 16) {
-        mfma_d4 acc[WM_MAX_TILES];
+    for (int r0 = rt * 16; r0 < Lj; r0 += nrg * 16) {
+        mfma_d4 acc[TILES];
 #pragma unroll
-        for (int t = 0; t < WM_MAX_TILES; t++) acc[t] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < TILES; t++) acc[t] = mfma_d4{0.0, 0.0, 0.0, 0.0};
         for (int qc = q_lo; qc < q_hi; qc += WM_QC) {
-            __syncthreads();                                // the previous trip's fragments have been read
-            if (tid < WM_QC) {
-                const int qq = qc + tid;
-                const int pos = qq < q_hi ? (qq < p0 ? qq : qq + m) : -1;      // positions outside the window keep their place
-                s_pos[tid] = pos;
-                s_col[tid] = pos >= 0 ? pos2sel[pos] : 0;
+            const int cols = q_hi - qc < WM_QC ? q_hi - qc : WM_QC;
+            if (q_hi - q_lo > WM_QC || r0 == rt * 16) {     // a slice of one trip keeps its positions over the row tiles
+                __syncthreads();                            // the previous trip's fragments have been read
+                if (tid < WM_QC) {
+                    const int qq = qc + tid;
+                    const int pos = tid < cols ? (qq < p0 ? qq : qq + m) : -1;     // positions outside the window keep their place
+                    s_pos[tid] = pos;
+                    s_col[tid] = pos >= 0 ? pos2sel[pos] : 0;
+                }
             }
             __syncthreads();
-            for (int e = tid; e < 16 * WM_QC; e += 256) {   // 16 rows x 64 columns, coalesced along q
-                const int r = e / WM_QC, c = e - r * WM_QC;
-                const bool ok = r0 + r < Lj && s_pos[c] >= 0;
-                As[r * (WM_QC + 1) + c] = ok ? M2[(int64_t)(startj + r0 + r) * ld2 + s_col[c]] : 0.0;
+            {                                               // 16 rows x WM_QC columns, coalesced along q, all loads in flight
+                constexpr int RPT = 16 * WM_QC / 256;       // rows per thread
+                const int cq = tid % WM_QC, rb = (tid / WM_QC) * RPT;
+                const int c = s_col[cq];
+                const bool okc = cq < cols;
+                double v[RPT];
+#pragma unroll
+                for (int r = 0; r < RPT; r++)
+                    v[r] = okc && r0 + rb + r < Lj ? M2[(int64_t)(startj + r0 + rb + r) * ld2 + c] : 0.0;
+#pragma unroll
+                for (int r = 0; r < RPT; r++) As[(rb + r) * (WM_QC + 1) + cq] = v[r];
             }
             __syncthreads();
-#pragma unroll 4
-            for (int kk = 0; kk < WM_QC / 4; kk++) {
+            const int kk_end = (cols + 3) >> 2;
+#pragma unroll 2
+            for (int kk = 0; kk < kk_end; kk++) {
                 const int kq = kk * 4 + (lane >> 4);
                 const double a = As[(lane & 15) * (WM_QC + 1) + kq];
-                const int pos = s_pos[kq];
+                int pos = s_pos[kq];
+                pos = pos < 0 ? p0 : pos;                   // a padded column carries a == 0: any finite weight does
 #pragma unroll
-                for (int t = 0; t < WM_MAX_TILES; t++) {
+                for (int t = 0; t < TILES; t++) {
                     const int st = wave + 4 * t;
                     if (st < n_tiles) {                     // uniform per wave
                         int d = p0 + st * 16 + (lane & 15) - pos;
                         d = d < 0 ? -d : d;
-                        d = d < 1 ? 1 : (d > n - 1 ? n - 1 : d);    // padded rows / columns carry a == 0: any finite weight does
+                        d = d < 1 ? 1 : (d > n - 1 ? n - 1 : d);    // padded rows / columns carry a == 0
                         const double b = hn - H[d - 1];
                         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
                     }
@@ -197,7 +239,7 @@ __global__ __launch_bounds__(256) void k_win_outside_mfma(const double* __restri
         }
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < WM_MAX_TILES; t++) {
+        for (int t = 0; t < TILES; t++) {
             const int st = wave + 4 * t;
             if (st < n_tiles) {
 #pragma unroll
@@ -212,6 +254,7 @@ __global__ __launch_bounds__(256) void k_win_outside_mfma(const double* __restri
                 qacc += Gt[r * m_pad_max + e_off + (e_rev ? Lj - 1 - i : i)];
             }
         }
+        __syncthreads();                                    // Gt shares As
     }
     if (tid < n_entries) Q[((int64_t)e_rev << k) | spread_bit(tid & ((1 << (k - 1)) - 1), j)] = qacc;
 }
@@ -256,6 +299,18 @@ __global__ __launch_bounds__(256) void k_win_pairs(const double* __restrict__ M2
         if (lane == 0) s_part[wave] = acc;
         __syncthreads();
         if (tid == 0) base[WT_SLICES * wt_q_size(k) + wt_p_size(k) + a] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        // the partial outside tables of scaffold a (k_win_outside*, earlier on this stream) are added into slice 0
+        int nrg, nq;
+        wt_split(La, m, n - m, nrg, nq);
+        const int nz = nrg * nq;
+        const int64_t q_size = wt_q_size(k);
+        for (int e = tid; e < (2 << k) && nz > 1; e += 256) {
+            if ((e >> a) & 1) continue;                     // (scaffold a is never in its own "before" set)
+            double* __restrict__ q0 = base + (((int64_t)a * 2) << k) + e;
+            double sum = q0[0];
+            for (int z = 1; z < nz; z++) sum += q0[z * q_size];
+            q0[0] = sum;
+        }
         return;
     }
     const int Lb = s_len[b], startb = we.w.start[b];
@@ -317,8 +372,7 @@ __global__ __launch_bounds__(256) void k_win_candidates(int k, const int8_t* __r
     for (int s = 0; s < k; s++) {
         const int a = ord[s], ra = ori[s] ? 1 : 0;
         const int64_t qi = ((int64_t)(a * 2 + ra) << k) | before;
-#pragma unroll
-        for (int z = 0; z < WT_SLICES; z++) sum += Q[z * q_size + qi];
+        sum += Q[qi];                                       // (slice 0 holds the sum of the partial tables)
         int between = 0;
         for (int t = s + 1; t < k; t++) {
             const int b = ord[t], rb = ori[t] ? 1 : 0;
@@ -330,11 +384,11 @@ __global__ __launch_bounds__(256) void k_win_candidates(int k, const int8_t* __r
     delta_all[(int64_t)blockIdx.y * n_cand + c] = sum;
 }
 
-static std::atomic<int> g_lds_out{0}, g_lds_pairs{0}, g_lds_mfma{0}, g_lds_mfma2{0};
+static std::atomic<int> g_lds_out{0}, g_lds_pairs{0};
 
 // tables: n_win * window_table_doubles(k) doubles of scratch; delta_all: n_win x (n_ord * n_ori)
 void launch_p2_window_tables(const double* M2, int64_t ld2, const int32_t* pos2sel, int n, int k,
-                             const WindowBatchEntry* wb, int n_win, int max_m, const int8_t* orders, const uint8_t* orients,
+                             const WindowBatchEntry* wb, const WindowBatchEntry* h_wb, int n_win, int max_m, const int8_t* orders, const uint8_t* orients,
                              int n_ord, int n_ori, const double* H, double* tables, double* delta_all, hipStream_t s)
 {
     if (n_win <= 0 || k < 1) return;
@@ -344,24 +398,36 @@ void launch_p2_window_tables(const double* M2, int64_t ld2, const int32_t* pos2s
     // the outside table through the matrix cores (v_mfma_f64_16x16x4_f64) for windows of up to 512 bins and at most 256
     // table entries per scaffold (k <= 8); HICMI_P2_WINDOW_VALU=1 keeps the vector-ALU kernel (A/B)
     const int m_pad_max = (max_m + 15) & ~15;
-    const size_t lds_mfma = ((size_t)16 * (WM_QC + 1) + (size_t)16 * m_pad_max) * sizeof(double);
-    static const bool valu_only = getenv("HICMI_P2_WINDOW_VALU") != nullptr;
-    if (!valu_only && m_pad_max <= 16 * 4 * WM_MAX_TILES && k <= 8 && lds_mfma <= 96 * 1024) {
-        if (lds_mfma + h_all <= 144 * 1024) {
-            ensure_dynamic_lds(reinterpret_cast<const void*>(k_win_outside_mfma<true>), g_lds_mfma, lds_mfma + h_all);
-            hipLaunchKernelGGL(k_win_outside_mfma<true>, dim3(k, n_win, WT_SLICES), dim3(256), lds_mfma + h_all, s, M2, ld2, pos2sel, n, k,
-                               wb, H, tables, stride, m_pad_max);
-        } else {
-            ensure_dynamic_lds(reinterpret_cast<const void*>(k_win_outside_mfma<false>), g_lds_mfma2, lds_mfma);
-            hipLaunchKernelGGL(k_win_outside_mfma<false>, dim3(k, n_win, WT_SLICES), dim3(256), lds_mfma, s, M2, ld2, pos2sel, n, k, wb,
-                               H, tables, stride, m_pad_max);
+    // grid z = the most partial tables any (window, scaffold) of the batch asks for
+    int n_slices = 1;
+    for (int w = 0; w < n_win; w++)
+        for (int j = 0; j < k; j++) {
+            int nrg, nq;
+            wt_split(h_wb[w].w.len[j], h_wb[w].m, n - h_wb[w].m, nrg, nq);
+            n_slices = nrg * nq > n_slices ? nrg * nq : n_slices;
         }
+    const size_t lds_mfma = (size_t)16 * (size_t)(WM_QC + 1 > m_pad_max ? WM_QC + 1 : m_pad_max) * sizeof(double);
+    static const bool valu_only = getenv("HICMI_P2_WINDOW_VALU") != nullptr;
+    if (!valu_only && m_pad_max <= 16 * 4 * WM_MAX_TILES && k <= 8) {
+        const bool h_lds = lds_mfma + h_all <= 150 * 1024;
+        const size_t lds = lds_mfma + (h_lds ? h_all : 0);
+        const int tiles = m_pad_max <= 128 ? 2 : (m_pad_max <= 256 ? 4 : 8);
+#define HICMI_WIN_MFMA(HL, T)                                                                                                   \
+        do {                                                                                                                    \
+            static std::atomic<int> lds_set{0};                                                                                 \
+            ensure_dynamic_lds(reinterpret_cast<const void*>(k_win_outside_mfma<HL, T>), lds_set, lds);                         \
+            hipLaunchKernelGGL((k_win_outside_mfma<HL, T>), dim3(k, n_win, n_slices), dim3(256), lds, s, M2, ld2, pos2sel, n, k, \
+                               wb, H, tables, stride, m_pad_max);                                                               \
+        } while (0)
+        if (h_lds) { if (tiles == 2) HICMI_WIN_MFMA(true, 2); else if (tiles == 4) HICMI_WIN_MFMA(true, 4); else HICMI_WIN_MFMA(true, 8); }
+        else       { if (tiles == 2) HICMI_WIN_MFMA(false, 2); else if (tiles == 4) HICMI_WIN_MFMA(false, 4); else HICMI_WIN_MFMA(false, 8); }
+#undef HICMI_WIN_MFMA
     }
     else if (h_all <= 96 * 1024) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(k_win_outside<true>), g_lds_out, h_all);
-        hipLaunchKernelGGL(k_win_outside<true>, dim3(k, n_win, WT_SLICES), dim3(256), h_all, s, M2, ld2, pos2sel, n, k, wb, H, tables, stride);
+        hipLaunchKernelGGL(k_win_outside<true>, dim3(k, n_win, n_slices), dim3(256), h_all, s, M2, ld2, pos2sel, n, k, wb, H, tables, stride);
     } else {
-        hipLaunchKernelGGL(k_win_outside<false>, dim3(k, n_win, WT_SLICES), dim3(256), 0, s, M2, ld2, pos2sel, n, k, wb, H, tables, stride);
+        hipLaunchKernelGGL(k_win_outside<false>, dim3(k, n_win, n_slices), dim3(256), 0, s, M2, ld2, pos2sel, n, k, wb, H, tables, stride);
     }
     if (h_win <= 96 * 1024) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(k_win_pairs<true>), g_lds_pairs, h_win);
