@@ -324,7 +324,10 @@ class Job:
                                f("chromosomeOrders.txt"), f("plotOrder.txt"), a.n_scaffolds, a.scan_scaffolds,
                                self.lay.resolution, shard=self.shard, chromosomeList=dm.chromosome_groups,
                                on_native_phase=dm.release_files)
+            tf = time.perf_counter()
             dm.finish_files()
+            if os.environ.get("HICMI_PART2_PROFILE"):
+                sys.stderr.write("[bench] waited %.1f ms for Part 1's background files\n" % ((time.perf_counter() - tf) * 1e3))
             if self.shard is not None and not a.part1_only:
                 groups = dm.chromosome_groups
                 mine = p2.chromosomesOfRank(groups, self.shard[0], self.shard[1])

@@ -34,7 +34,7 @@ SCORE_HOOK = None      # tests: called with the fast scores of every step, in en
 _PROFILE = bool(os.environ.get("HICMI_PART2_PROFILE"))   # per-chromosome wall clock on stderr
 WORKERS = int(os.environ.get("HICMI_PART2_WORKERS", "8"))
 LOCKSTEP = os.environ.get("HICMI_PART2_LOCKSTEP", "1") != "0"   # all chromosomes' insertion loops in one queue of launches   # chromosomes ordered concurrently (1 = sequential)
-START_THREADS = os.environ.get("HICMI_PART2_START_THREADS", "0") != "0"   # A/B: the start phase on the worker threads
+START_THREADS = int(os.environ.get("HICMI_PART2_START_THREADS", "0"))   # A/B: the start phase on this many threads (0: the calling thread)
 NEAR_TOP = 1e-9        # relative band around a step's best fast score that is re-scored literally
 
 
@@ -717,6 +717,8 @@ def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds
         lanes = dict(zip(indices, lanes))
         todo = sorted(indices, key=lambda i: -len(chromList[i]))                    # largest first
         marks = [time.perf_counter()]
+        if _PROFILE:
+            sys.stderr.write("[hicmi] part2 set-up (bin index, one context per chromosome): %.1f ms\n" % ((marks[0] - t0p) * 1e3))
 
         def start(i):
             print("#####################\n#####################")
@@ -726,7 +728,11 @@ def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds
             # the start phase runs on THIS thread, one chromosome after the other: it is half interpreter work and half
             # short native calls, and threads that hand the interpreter lock to each other at every one of those calls
             # took 12-14 ms (16k) / 22-24 ms (32k) where the plain loop takes 7.7 / 13.5 ms
-            states = dict(pool.map(start, todo)) if START_THREADS else dict(map(start, todo))
+            if START_THREADS > 0:
+                with ThreadPoolExecutor(max_workers=START_THREADS) as starters:
+                    states = dict(starters.map(start, todo))
+            else:
+                states = dict(map(start, todo))
             marks.append(time.perf_counter())
             jobs, job_of, inserted = [], [], {}
             for i in todo:
@@ -819,13 +825,15 @@ def writeScaffoldOrderingsToFile(sOrderings, outFile):
 
 def writeBinIDsOrderingToFile(scaffoldList, outFile):
     """OG:646-660: header line, then newline-PREFIXED rows (no trailing newline)."""
-    rows = ["#ScaffoldID\tHiCPro-BinID"]
+    rows, n_rows = ["#ScaffoldID\tHiCPro-BinID"], 0
     for s in scaffoldList:
-        head = "\n" + s.name + "\t"
-        rows.extend([head + str(b) for b in s.binList])
+        if len(s.binList):
+            head = "\n" + s.name + "\t"
+            rows.append(head + head.join(map(str, s.binList)))
+            n_rows += len(s.binList)
     with open(outFile, "w") as fh:
         fh.write("".join(rows))
-    print("BinIDs written to file " + str(len(rows) - 1))
+    print("BinIDs written to file " + str(n_rows))
 
 
 def getChromosomeOutlineCoords(orderedChromosomes):
@@ -891,7 +899,10 @@ def runResident(adjMat: GenomeMatrix, binList, chromosomeGroupFile, chromosomeOr
                                          scanScaffolds=scanScaffolds, plotChrom=True, showPlot=False,
                                          savePlotDir=savePlotDir, plotTitleSuffix=plotTitleSuffix, shard=shard,
                                          on_native_phase=on_native_phase)
+        tw = time.perf_counter()
         if shard is None or shard[0] == 0:
             writeScaffoldOrderingsToFile(orderedChromosomes, chromosomeOrderFile)
             writeBinIDsOrderingToFile([s for group in orderedChromosomes for s in group], plotOrderFile)
+        if _PROFILE:
+            sys.stderr.write("[hicmi] part2 files: %.1f ms\n" % ((time.perf_counter() - tw) * 1e3))
     return orderedChromosomes
