@@ -684,6 +684,10 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         HIPCHK(hipMalloc((void**)&c->d_zraw, sizeof(double) * 4 * (size_t)n));
         HIPCHK(hipMalloc((void**)&c->d_status, sizeof(int)));
     }
+    static const bool step_prof = getenv("HICMI_STEP_PROFILE") != nullptr;
+    std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> marks;
+    auto mark = [&](const char* what) { if (step_prof) marks.emplace_back(what, std::chrono::steady_clock::now()); };
+    mark("start");
     {
         Timed t(c, F_BUILD_W, 8.0 * (0.5 * (double)n * (double)n + (double)n * (double)n));
         launch_build_w(c->dC, c->ldc, c->d_np, (int)n, c->dW, ldw, c->stream);
@@ -691,6 +695,7 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
     HIPCHK(hipGetLastError());
     rc = start_presort(c);                                         // beside the chain, on the second stream
     if (rc) return rc;
+    mark("build_w + pre-sort queued");
     // The nn-chain.  Algorithmic bytes: 8 B x (sum over row scans of the live columns + 3 x sum over merges
     // of the live columns), with the scans counted by the kernels themselves (a scan the neighbour cache answers moves
     // nothing); the merge term is 3 * 8 * sum_{k=0}^{n-2} (n - k).
@@ -723,11 +728,13 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         launch_build_w(c->dC, c->ldc, c->d_np, (int)n, c->dW, ldw, c->stream);
         HIPCHK(hipGetLastError());
     }
+    mark("chain (epochs, compactions, state)");
     c->zraw.assign((size_t)(4 * (n - 1)), 0.0);
     {
         int rc_dl = download(c, c->zraw.data(), c->d_zraw, sizeof(double) * 4 * (size_t)(n - 1));
         if (rc_dl) return rc_dl;
     }
+    mark("merge records to the host");
     if (prof_on) {
         const unsigned long long* pr = nn.prof;
         fprintf(stderr, "[hicmi] nnchain phases (ms @100MHz): bookkeeping %.2f scan %.2f pick %.2f merge %.2f update %.2f; "
@@ -757,9 +764,17 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
     std::vector<double> Z((size_t)(4 * (n - 1)));
     rc = hicmi_label_linkage(c->zraw.data(), n, Z.data());
     if (rc) return rc;
+    mark("sort + label");
     rc = hicmi_leaf_order(Z.data(), n, leaves_out);
     if (rc) return rc;
     if (Z_out) memcpy(Z_out, Z.data(), sizeof(double) * Z.size());
+    mark("leaf order");
+    if (step_prof) {
+        fprintf(stderr, "[hicmi] upgma host timeline (ms):");
+        for (size_t i = 1; i < marks.size(); i++)
+            fprintf(stderr, " %s %.2f%s", marks[i].first, std::chrono::duration<double, std::milli>(marks[i].second - marks[i - 1].second).count(),
+                    i + 1 < marks.size() ? "," : "\n");
+    }
     return HICMI_OK;
 }
 

@@ -24,6 +24,8 @@ device-resident matrix by plotContactMaps.py (exact percentiles, figure-resoluti
 """
 from __future__ import annotations
 
+import collections
+import operator
 import os
 import sys
 import time
@@ -397,9 +399,7 @@ def readBinGroupingsFromFile(binGroupingsFile):
 
 def _assess_group(pairs, scaffDict, out, percentToAssign):
     """assessClusterList on (bin, scaffold) pairs; ``out`` collects the report lines."""
-    members = {}
-    for bin_id, scaff in pairs:
-        members[scaff] = members.get(scaff, 0) + 1
+    members = collections.Counter(map(_second, pairs))       # (a dict: scaffolds in order of first appearance)
     final, assigned, false_pos = [], 0, 0
     out.append("#Scaffold\tNodesAssigend\tTotalNodes\tAssigned%\n")
     for s, have in members.items():
@@ -416,16 +416,33 @@ def _assess_group(pairs, scaffDict, out, percentToAssign):
     return final, false_pos, assigned
 
 
+_second = operator.itemgetter(1)
+
+
+class PairList(list):
+    """A group that is known to hold (bin, scaffold) pairs only (_bin_group_pairs): _pairs_of_lines passes it through."""
+
+
 def _pairs_of_lines(cList):
     """(bin, scaffold) of every bin-grouping line; entries that already are such pairs pass through."""
+    if isinstance(cList, PairList):
+        return cList
     return [line if isinstance(line, tuple) else tuple(line.split("\t", 2)[:2]) for line in cList]
 
 
-def _bin_group_pairs(coords, binList):
+def _bin_pairs(binList):
+    """{bin ID: (bin ID text, scaffold)} - independent of the grouping, so runResident builds it beside the chain."""
+    return {b.ID: (str(b.ID), b.chrom) for b in binList}
+
+
+def _bin_group_pairs(coords, binList, pairs=None):
     """What readBinGroupingsFromFile + the split in assessChromosomeClustering extract from the bin-grouping file:
-    per group the (bin ID text, scaffold) pairs - taken from the bins themselves."""
+    per group the (bin ID text, scaffold) pairs - taken from the bins themselves (``pairs``: _bin_pairs of them)."""
     bounds = [0] + [int(c) for c in coords] + [len(binList)]
-    return [[(str(b.ID), b.chrom) for b in binList[bounds[g]:bounds[g + 1]]] for g in range(len(bounds) - 1)]
+    if pairs is None:
+        return [PairList((str(b.ID), b.chrom) for b in binList[bounds[g]:bounds[g + 1]]) for g in range(len(bounds) - 1)]
+    ids = [b.ID for b in binList]
+    return [PairList(map(pairs.__getitem__, ids[bounds[g]:bounds[g + 1]])) for g in range(len(bounds) - 1)]
 
 
 def assessClusterList(cList, scaffDict, outFile, percentToAssign=51.):
@@ -614,6 +631,7 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
             prep["labels"] = [b.chrom + '_' + str(b.ID) for b in bl]
             prep["sizes"] = readSizeFileToDict(hicProScaffSizeFile)
             prep["scaffolds"] = _scaffold_bins((b.ID, b.chrom) for b in bl)
+            prep["pairs"] = _bin_pairs(bl)
         dendrogram = averageClusterNodes(adjMat, lambda: prep["labels"], noPlot=True, meanwhile=meanwhile)
         mark("UPGMA + leaf order")
         # the reference parses the file back (readDengrogramLeavesFromFile); the leaves are the same integers
@@ -642,7 +660,7 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
                                                                           cutIndices, n_rounds=louvainRounds)
                 adjMat, binList = reorderMatrix(adjMat, binList, new_order)
         writer.submit(writeBinGroupingsToFile, list(cutIndices), list(binList), binGroupFile, deferred=True)
-        binGroups = _bin_group_pairs(cutIndices, binList)
+        binGroups = _bin_group_pairs(cutIndices, binList, prep["pairs"])
         print("Total run-time to identify chromosome boundaries = " + str(time.time() - t0))
         t0 = time.time()
         fastaSizeDict = prep["sizes"]
