@@ -652,6 +652,55 @@ def test_p2_device_enumeration_matches_explicit_candidates(hic, orc):
                 assert np.allclose(got, want, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("lens, k", [
+    ([150, 40, 90, 17, 200, 33, 60, 5, 310, 280, 12, 1, 450], 3),     # 2 / 4 / 8 slot tiles per wave, 1 ... 20 row tiles
+    ([300, 250, 100, 64, 16, 700, 15], 3),                             # windows beyond 512 bins: the vector-ALU tables
+    ([31, 7, 16, 48, 2, 90, 25, 130, 11, 64, 5, 77, 1200], 5),         # k = 5 with one scaffold far heavier than the rest
+])
+def test_p2_window_tables_with_wide_windows_and_long_scaffolds(hic, orc, lens, k):
+    """The placement tables (k_part2_window.hip) where their work split matters: windows of 100 ... 700 bins, scaffolds of
+    1 ... 450 bins (wt_split: several groups of row tiles x several column slices per scaffold, partial tables added by
+    k_win_pairs), every kernel instantiation - against the same candidates spelled out and scored by hicmi_p2_score."""
+    from hic_genome_assembler_amd import orderGenome as p2
+    rng = np.random.default_rng(len(lens) * 100 + k)
+    n = sum(lens)
+    starts = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int32)
+    m = rng.random((n + 3, n + 3)); m = m + m.T
+    sel = rng.permutation(n + 3)[:n].astype(np.int32)
+
+    def pos(sid, rev):
+        a = np.arange(starts[sid], starts[sid] + lens[sid], dtype=np.int32)
+        return a[::-1] if rev else a
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(m)
+        ctx.p2_select(sel)
+        ctx.p2_layout(starts, np.asarray(lens, np.int32))
+        ids = rng.permutation(len(lens)).astype(np.int32)
+        rev = rng.integers(0, 2, len(lens)).astype(np.uint8)
+        pieces = [pos(i, r) for i, r in zip(ids, rev)]
+        base = np.concatenate(pieces)
+        ctx.p2_set_arrangement(ids, rev)
+        total = ctx.p2_arrangement_total()
+        s_arr = ctx.p2_arrangement_score(total)
+        orders, orients = p2._enumeration(k)
+        ctx.p2_window_tables(np.asarray(orders, np.int8),
+                             np.asarray([[1 if sg == "-" else 0 for sg in r] for r in orients], np.uint8))
+        pick = rng.permutation(len(orders) * len(orients))[:24]          # candidates spelled out per window
+        for first in range(0, len(ids) - k + 1):
+            delta = ctx.p2_score_window(first, k)
+            head = np.concatenate(pieces[:first]) if first else np.zeros(0, np.int32)
+            tail = np.concatenate(pieces[first + k:]) if first + k < len(ids) else np.zeros(0, np.int32)
+            c0 = p2._orient_index(k, ["-" if v else "+" for v in rev[first:first + k]])
+            rows = []
+            for c in pick:
+                o, r = orders[c // len(orients)], orients[c % len(orients)]
+                mid = [pos(int(ids[first + j]), sg == "-") for j, sg in zip(o, r)]
+                rows.append(np.concatenate([head] + mid + [tail]))
+            want = ctx.p2_score(np.stack(rows), total)
+            got = s_arr + (delta[pick] - delta[c0]) / total
+            assert np.allclose(got, want, rtol=1e-11, atol=0), (first, np.max(np.abs(got - want) / np.abs(want)))
+
+
 # --------------------------------------------------------------------------------- end to end
 def _run_product(name, tmp_path, record=None):
     from hic_genome_assembler_amd import scaffoldToChromosomes as p1, orderGenome as p2
