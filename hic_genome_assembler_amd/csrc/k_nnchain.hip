@@ -1787,6 +1787,24 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
         // ---- merge (top, second); the row the chain returns to - `a` - is scanned in the same pass if it needs it
         int mx = top, my = second;                              // (uniform)
         if (mx > my) { const int t = mx; mx = my; my = t; }
+        // the loads that only need (x, y) go out BEFORE the chain bookkeeping - sizes, the height, both streamed rows - so
+        // that they land while ~0.8 us of serial code runs; row a's loads follow once a is known and land during the
+        // Lance-Williams pass over x and y
+        const double* __restrict__ rx = W + (int64_t)mx * ld;
+        double* __restrict__ ry = W + (int64_t)my * ld;
+        const __amdgpu_buffer_rsrc_t bx = w1_row(rx, (c1 + 1) & ~1), by = w1_row(ry, (c1 + 1) & ~1);
+        int r_nx = __hip_atomic_load(gsize + mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int r_ny = __hip_atomic_load(gsize + my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long r_h = 0, r_dp = 0;
+        if (lane == 62) r_h = w1_ld8(rx + my);                   // the merge height d(x, y)
+        u32x4 qa[TRIPS], qb[TRIPS], qc[TRIPS];
+#pragma unroll
+        for (int t = 0; t < TRIPS; t++) {
+            const int off = (jl0 + 2 * t) * 8;
+            qa[t] = w1_ld16(bx, off);
+            qb[t] = w1_ld16(by, off);
+        }
+        NN_FENCE();
         len -= 2;
         if (lane == 0) meta[mx] = 0xff000000u | W1_NOIDX;       // x is dead
         if (len < lowmark) lowmark = len;
@@ -1809,30 +1827,19 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
         unsigned long long evm = 0ull;
         double dprev = __builtin_inf(), fs = 0.0;
         {
-            const double* __restrict__ rx = W + (int64_t)mx * ld;
-            double* __restrict__ ry = W + (int64_t)my * ld;
             const double* __restrict__ ra = W + (int64_t)(a >= 0 ? a : mx) * ld;
-            // ---- issue every load: sizes, the height, d(a, prev), the streamed pairs (nothing waits yet)
-            const __amdgpu_buffer_rsrc_t bx = w1_row(rx, (c1 + 1) & ~1), by = w1_row(ry, (c1 + 1) & ~1), ba = w1_row(ra, (c1 + 1) & ~1);
-            int r_nx = __hip_atomic_load(gsize + mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int r_ny = __hip_atomic_load(gsize + my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned long long r_h = 0, r_dp = 0;
-            if (lane == 62) r_h = w1_ld8(rx + my);                   // the merge height d(x, y)
+            const __amdgpu_buffer_rsrc_t ba = w1_row(ra, (c1 + 1) & ~1);
             if (lane == 63 && aprev >= 0) r_dp = w1_ld8(ra + aprev);
-            u32x4 qa[TRIPS], qb[TRIPS], qc[TRIPS];
 #pragma unroll
             for (int t = 0; t < TRIPS; t++) {
-                const int off = (jl0 + 2 * t) * 8;
-                qa[t] = w1_ld16(bx, off);
-                qb[t] = w1_ld16(by, off);
                 qc[t] = u32x4{0u, 0u, 0u, 0u};
-                if (a >= 0) qc[t] = w1_ld16(ba, off);
+                if (a >= 0) qc[t] = w1_ld16(ba, (jl0 + 2 * t) * 8);
             }
             NN_FENCE();
             W1_STAMP(4);
-            NN_KEEP(r_nx); NN_KEEP(r_ny); NN_KEEP(r_h); NN_KEEP(r_dp);
+            NN_KEEP(r_nx); NN_KEEP(r_ny); NN_KEEP(r_h);
 #pragma unroll
-            for (int t = 0; t < TRIPS; t++) { NN_KEEP(qa[t]); NN_KEEP(qb[t]); NN_KEEP(qc[t]); }
+            for (int t = 0; t < TRIPS; t++) { NN_KEEP(qa[t]); NN_KEEP(qb[t]); }
             W1_STAMP(5);
             const int nx = __builtin_amdgcn_readfirstlane(r_nx), ny = __builtin_amdgcn_readfirstlane(r_ny);
             if (lane == 0) { st4_sc1(gsize + mx, 0); st4_sc1(gsize + my, nx + ny); }
@@ -1851,7 +1858,6 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
                 const double2 xa = mw_pair(qa[t]);
                 const double2 bo = mw_pair(qb[t]);
                 double2 b;
-                const double2 va = mw_pair(qc[t]);
                 const double2 nv = *reinterpret_cast<const double2*>(nnv + (jj - c0));
                 const uint2 m2 = *reinterpret_cast<const uint2*>(meta + jj);
                 const bool w0 = in && (m2.x >> 24) != 255u && j != my, w1 = in && (m2.y >> 24) != 255u && j + 1 != my;
@@ -1861,11 +1867,8 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
                 w1_upd(rbest, w1, b.y, j + 1);
                 ev = ev || (w0 && (m2.x & W1_NOIDX) != W1_NOIDX && b.x <= nv.x) || (w1 && (m2.y & W1_NOIDX) != W1_NOIDX && b.y <= nv.y);
                 if (a >= 0) {                                   // (uniform)
-                    const bool is0 = j == a, is1 = j + 1 == a;
-                    if (w0 && is0) { ya = b.x; has_ya = true; }
-                    if (w1 && is1) { ya = b.y; has_ya = true; }
-                    w1_upd(abest, w0 && !is0, va.x, j);
-                    w1_upd(abest, w1 && !is1, va.y, j + 1);
+                    if (w0 && j == a) { ya = b.x; has_ya = true; }
+                    if (w1 && j + 1 == a) { ya = b.y; has_ya = true; }
                 }
                 // row y': the pair goes back as one 16-byte store - elements that were not recomputed (the diagonal, dead
                 // columns) carry the value just loaded; column y': the recomputed values at W[j][y'], one scattered 8-byte
@@ -1881,6 +1884,21 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
                 }
             }
             W1_STAMP(6);
+            // row a: its loads went out after the bookkeeping and have had the pass above to land
+            NN_KEEP(r_dp);
+#pragma unroll
+            for (int t = 0; t < TRIPS; t++) NN_KEEP(qc[t]);
+            if (a >= 0) {                                       // (uniform)
+#pragma unroll
+                for (int t = 0; t < TRIPS; t++) {
+                    const int j = jl0 + 2 * t;
+                    const bool in = j < c1;
+                    const double2 va = mw_pair(qc[t]);
+                    const uint2 m2 = *reinterpret_cast<const uint2*>(meta + (in ? j : c0));
+                    w1_upd(abest, in && (m2.x >> 24) != 255u && j != my && j != a, va.x, j);
+                    w1_upd(abest, in && (m2.y >> 24) != 255u && j + 1 != my && j + 1 != a, va.y, j + 1);
+                }
+            }
             if (aprev >= 0) dprev = bcast_f64(r_dp, 63);
             rbest = argmint_wave_mono(rbest);
             if (a >= 0) {
