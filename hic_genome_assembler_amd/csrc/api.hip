@@ -651,6 +651,8 @@ static int start_presort(hicmi_ctx* c)
         x.tie_limit = (unsigned)n;                                 // (never gives up: tied rows are finished by k_rank_rows_tied)
         x.tie_bits = c->d_tie_bits; x.ld_bits = ld_bits;
         x.max_workgroups = 192;                                    // (the chain: up to 64 single-wave workgroups, one CU each)
+        x.avoid_xcc = nnchain_local_xcc((int)n);                   // ... all on one XCD, which this kernel's workgroups leave alone
+        x.row_counter = reinterpret_cast<unsigned*>(c->d_ties) + 1;     // (zeroed with the tie count just above)
         launch_sort_rows(c->dC, c->ldc, c->d_ident, c->d_ident, c->d_np, c->d_seq, (int)n, c->d_sort_scratch, c->dR, ldr, 0, 1,
                          c->stream2, x);
         launch_rank_invert(c->dR, c->dRankS, ldr, (int)n, 0, 1, c->stream2);

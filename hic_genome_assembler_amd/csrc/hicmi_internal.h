@@ -189,7 +189,12 @@ struct SortExtras {                        // optional modes of launch_sort_rows
     uint8_t* tie_flag = nullptr; unsigned* tie_count = nullptr; unsigned tie_limit = 0;   // flag rows holding equal keys
     uint16_t* tie_bits = nullptr; int64_t ld_bits = 0;        // ... and which sorted elements repeat the key before them
     int max_workgroups = 0;                                    // cap on the grid (0: the default)
+    int avoid_xcc = -1; unsigned* row_counter = nullptr;       // leave this XCD to another kernel; rows dealt out by a (zeroed) counter
 };
+// s_getreg operand of HW_REG_XCC_ID (id 20), bits 3:0: which of the 8 XCDs a wave runs on
+static constexpr int GETREG_XCC_ID = 20 | (0 << 6) | (3 << 11);
+// The XCD the nn-chain's one-wave kernel claims for itself (k_nnchain.hip), or -1 when it runs spread over all of them
+int nnchain_local_xcc(int n);
 void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const int32_t* inv, const double* np_sum,
                       const double* seq_sum, int n, void* scratch, uint16_t* R, int64_t ldr, int row_first, int row_stride,
                       hipStream_t s, const SortExtras& x = SortExtras());

@@ -812,6 +812,16 @@ __device__ __forceinline__ void st16_sc1(void* p, u32x4 v)
 {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
+// plain forms for workgroups that share an XCD (k_nn_epoch_w1, LOCAL): the line stays in that XCD's L2, where the peers'
+// sc1 loads find it - a hop of 0.28 us instead of 0.44, a 64-party exchange round of 0.70 us instead of 1.45
+__device__ __forceinline__ void st16_l2(void* p, u32x4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st8_l2(double* p, double v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ u32x4 ld16_sc1(const void* p)
 {
     u32x4 v;
@@ -1556,12 +1566,44 @@ __device__ __forceinline__ u32x4 w1_mail(double v, int idx, int tie, int ev, uns
 }
 __device__ __forceinline__ bool w1_mail_ready(u32x4 p, unsigned int seq) { return p.y == seq && (p.w >> 17) == (seq & 0x7fffu); }
 
-template <int TRIPS, bool PROF>
+// LOCAL: every party runs on the XCD `xcc_target` - the grid is 16 x S_arg single-wave workgroups, those that land
+// elsewhere leave at once and the first S_arg on the target claim the slices through a counter (w.state[15], zeroed by the
+// host) - so the stores a peer reads (mailboxes, the merged row and column) are PLAIN: they stay in the XCD's L2, which
+// the peers' sc1 loads read.  Which workgroups share an XCD is never assumed (MI355X_MICROARCH.md: placement is
+// undefined): a party knows its XCD from HW_REG_XCC_ID.  Should fewer than S_arg workgroups reach the target, or not all
+// be resident at once, the exchange's bounded spin ends the epoch as "a peer answered late" and the host re-runs the
+// chain without LOCAL.
+template <int TRIPS, bool PROF, bool LOCAL>
 __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int64_t ld, int n, int* __restrict__ chain_all,
-                                                    double* __restrict__ zraw, NNWorkspace w, int dcap, int total_steps, int slice)
+                                                    double* __restrict__ zraw, NNWorkspace w, int dcap, int total_steps, int slice,
+                                                    int S_arg, int xcc_target, int rollcall_need)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_nn[];
-    const int S = (int)gridDim.x, wg = (int)blockIdx.x, lane = (int)threadIdx.x;
+    const int lane = (int)threadIdx.x;
+    int S_ = (int)gridDim.x, wg_ = (int)blockIdx.x;
+    if (LOCAL) {
+        if ((int)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 0xfu) != xcc_target) return;
+        if (w1_uni(__hip_atomic_load(&w.state[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return;   // given up earlier in this chain
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&w.state[15], 1);
+        slot = w1_uni(slot);
+        if (slot >= S_arg) return;
+        // roll call, before anything is touched: a claimed slot is a RUNNING party, so the counter reaching S_arg says all
+        // of them are resident.  If it does not within ~2 ms (the XCD is busy with somebody else's kernels) the epoch is
+        // given up - state[12] - and the spread-out launch queued right behind this one runs it instead (xcc_target -2).
+        int claimed = 0, budget = 4000;
+        do {
+            claimed = w1_uni(__hip_atomic_load(&w.state[15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (claimed >= rollcall_need) break;
+            __builtin_amdgcn_s_sleep(8);
+        } while (--budget > 0);
+        if (claimed < rollcall_need) { if (lane == 0) atomicExch(&w.state[12], 1); return; }
+        if (w1_uni(__hip_atomic_load(&w.state[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return;
+        S_ = S_arg; wg_ = slot;
+    } else if (xcc_target == -2) {
+        if (w1_uni(__hip_atomic_load(&w.state[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;   // the LOCAL launch did the epoch
+    }
+    const int S = S_, wg = wg_;
     const int n4 = (n + 3) & ~3;
     uint32_t* meta = reinterpret_cast<uint32_t*>(smem_nn);   // idx | tie << 15 | stamp << 16 | mtime << 24, every slot
     double* nnv = reinterpret_cast<double*>(meta + n4);      // cached distances of the OWN columns (owner-private)
@@ -1642,8 +1684,13 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
         u32x4* box = mailw + (size_t)(xseq & 1u) * (NN_W1_MAXS * 2 * NN_W1_MAXS);
         if (lane < S && lane != wg) {
             u32x4* theirs = box + (size_t)lane * (2 * NN_W1_MAXS) + wg;
-            st16_sc1(theirs, w1_mail(m0.v, m0.i, m0.t, ev0, xseq));
-            if (two) st16_sc1(theirs + NN_W1_MAXS, w1_mail(m1.v, m1.i, m1.t, 0, xseq));
+            if (LOCAL) {
+                st16_l2(theirs, w1_mail(m0.v, m0.i, m0.t, ev0, xseq));
+                if (two) st16_l2(theirs + NN_W1_MAXS, w1_mail(m1.v, m1.i, m1.t, 0, xseq));
+            } else {
+                st16_sc1(theirs, w1_mail(m0.v, m0.i, m0.t, ev0, xseq));
+                if (two) st16_sc1(theirs + NN_W1_MAXS, w1_mail(m1.v, m1.i, m1.t, 0, xseq));
+            }
         }
         const u32x4* slots = box + (size_t)wg * (2 * NN_W1_MAXS);
         ArgMinT o0 = {__builtin_inf(), 0x7fffffff, 0}, o1 = {__builtin_inf(), 0x7fffffff, 0};
@@ -1878,9 +1925,14 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
                     u32x4 pk;
                     pk.x = (unsigned int)__double2loint(sx); pk.y = (unsigned int)__double2hiint(sx);
                     pk.z = (unsigned int)__double2loint(sy); pk.w = (unsigned int)__double2hiint(sy);
-                    __builtin_amdgcn_raw_buffer_store_b128(pk, by, j * 8, 0, 16);      // (sc1; lanes behind the slice are out of range: dropped)
-                    st8_sc1(w0 ? W + (int64_t)j * ld + my : dump, b.x);
-                    st8_sc1(w1 ? W + (int64_t)(j + 1) * ld + my : dump + 1, b.y);
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, by, j * 8, 0, LOCAL ? 0 : 16);      // (sc1 unless LOCAL; lanes behind the slice are out of range: dropped)
+                    if (LOCAL) {
+                        st8_l2(w0 ? W + (int64_t)j * ld + my : dump, b.x);
+                        st8_l2(w1 ? W + (int64_t)(j + 1) * ld + my : dump + 1, b.y);
+                    } else {
+                        st8_sc1(w0 ? W + (int64_t)j * ld + my : dump, b.x);
+                        st8_sc1(w1 ? W + (int64_t)(j + 1) * ld + my : dump + 1, b.y);
+                    }
                 }
             }
             W1_STAMP(6);
@@ -2201,21 +2253,29 @@ static int mwc_gsize_max_columns()
 // ---- k_nn_epoch_w1: slices, trips and LDS of one epoch ----------------------------------------------------------
 template <int TRIPS>
 static void launch_w1_t(bool profile, int S, int slice, size_t lds, hipStream_t s, double* cur, int64_t ldw, int n_cur, int* chain,
-                        double* zraw, NNWorkspace w, int dcap, int total_steps)
+                        double* zraw, NNWorkspace w, int dcap, int total_steps, int xcc, bool fail_rollcall)
 {
-    if (profile) hipLaunchKernelGGL((k_nn_epoch_w1<TRIPS, true>), dim3(S), dim3(64), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, slice);
-    else hipLaunchKernelGGL((k_nn_epoch_w1<TRIPS, false>), dim3(S), dim3(64), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, slice);
+    if (xcc >= 0) {                                              // LOCAL (see the kernel), and behind it the launch that takes over if it gives up
+        const int need = fail_rollcall ? 0x40000000 : S;          // (test hook: a party that never comes)
+        hipMemsetAsync(w.state + 15, 0, sizeof(int), s);
+        if (profile) hipLaunchKernelGGL((k_nn_epoch_w1<TRIPS, true, true>), dim3(16 * S), dim3(64), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, slice, S, xcc, need);
+        else hipLaunchKernelGGL((k_nn_epoch_w1<TRIPS, false, true>), dim3(16 * S), dim3(64), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, slice, S, xcc, need);
+        hipLaunchKernelGGL((k_nn_epoch_w1<TRIPS, false, false>), dim3(S), dim3(64), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, slice, S, -2, S);
+        return;
+    }
+    if (profile) hipLaunchKernelGGL((k_nn_epoch_w1<TRIPS, true, false>), dim3(S), dim3(64), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, slice, S, -1, S);
+    else hipLaunchKernelGGL((k_nn_epoch_w1<TRIPS, false, false>), dim3(S), dim3(64), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, slice, S, -1, S);
 }
 
 static void launch_w1(bool profile, int S, int slice, size_t lds, hipStream_t s, double* cur, int64_t ldw, int n_cur, int* chain,
-                      double* zraw, NNWorkspace w, int dcap, int total_steps)
+                      double* zraw, NNWorkspace w, int dcap, int total_steps, int xcc, bool fail_rollcall)
 {
     const int trips = (slice + 127) / 128;
-    if (trips <= 1) launch_w1_t<1>(profile, S, slice, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
-    else if (trips <= 2) launch_w1_t<2>(profile, S, slice, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
-    else if (trips <= 4) launch_w1_t<4>(profile, S, slice, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
-    else if (trips <= 8) launch_w1_t<8>(profile, S, slice, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
-    else launch_w1_t<16>(profile, S, slice, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
+    if (trips <= 1) launch_w1_t<1>(profile, S, slice, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, xcc, fail_rollcall);
+    else if (trips <= 2) launch_w1_t<2>(profile, S, slice, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, xcc, fail_rollcall);
+    else if (trips <= 4) launch_w1_t<4>(profile, S, slice, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, xcc, fail_rollcall);
+    else if (trips <= 8) launch_w1_t<8>(profile, S, slice, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, xcc, fail_rollcall);
+    else launch_w1_t<16>(profile, S, slice, lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, xcc, fail_rollcall);
 }
 
 // Dynamic LDS the kernels may ask for: what the CU has (160 KB) minus their static part.
@@ -2223,11 +2283,10 @@ static size_t w1_lds_room()
 {
     static size_t room = 0;
     if (room) return room;
-    const void* fns[] = {reinterpret_cast<const void*>(k_nn_epoch_w1<1, false>), reinterpret_cast<const void*>(k_nn_epoch_w1<1, true>),
-                         reinterpret_cast<const void*>(k_nn_epoch_w1<2, false>), reinterpret_cast<const void*>(k_nn_epoch_w1<2, true>),
-                         reinterpret_cast<const void*>(k_nn_epoch_w1<4, false>), reinterpret_cast<const void*>(k_nn_epoch_w1<4, true>),
-                         reinterpret_cast<const void*>(k_nn_epoch_w1<8, false>), reinterpret_cast<const void*>(k_nn_epoch_w1<8, true>),
-                         reinterpret_cast<const void*>(k_nn_epoch_w1<16, false>), reinterpret_cast<const void*>(k_nn_epoch_w1<16, true>)};
+#define W1_FNS(T) reinterpret_cast<const void*>(k_nn_epoch_w1<T, false, false>), reinterpret_cast<const void*>(k_nn_epoch_w1<T, true, false>), \
+                  reinterpret_cast<const void*>(k_nn_epoch_w1<T, false, true>), reinterpret_cast<const void*>(k_nn_epoch_w1<T, true, true>)
+    const void* fns[] = {W1_FNS(1), W1_FNS(2), W1_FNS(4), W1_FNS(8), W1_FNS(16)};
+#undef W1_FNS
     size_t stat = 0;
     for (const void* f : fns) {
         hipFuncAttributes a;
@@ -2259,6 +2318,30 @@ static bool w1_plan(int n, int cols, int max_s, int force_s, int* S_out, int* sl
     if (lds > w1_lds_room()) return false;
     *S_out = S; *slice_out = slice; *lds_out = lds;
     return true;
+}
+
+// The XCD the one-wave kernel claims (its LOCAL form), or -1: HICMI_NNCHAIN_XCD=off | 0..7 (default 0).  The pre-sort that runs
+// beside the chain leaves that XCD alone (api.hip: start_presort), so its 32 CUs are free for up to 64 parties.
+static int w1_xcc_env()
+{
+    const char* t = getenv("HICMI_NNCHAIN_XCD");          // off | 0 .. 7
+    if (!t) return 0;
+    return (t[0] < '0' || t[0] > '7') ? -1 : t[0] - '0';
+}
+
+// ... for the pre-sort's benefit: the XCD it should leave alone, i.e. the chain's XCD if the chain's FIRST epoch at n columns
+// already runs there.  (A wider map starts spread out - 8 parties per XCD, which the pre-sort's 192 workgroups leave room
+// for on every XCD - and by the time it has shrunk to one XCD's capacity the pre-sort is over.)
+int nnchain_local_xcc(int n)
+{
+    const int xcc = w1_xcc_env();
+    if (xcc < 0 || n > NN_W1_MAX) return -1;
+    const char* w1_text = getenv("HICMI_NNCHAIN_W1");
+    if ((w1_text && atoi(w1_text) == 0) || getenv("HICMI_NNCHAIN_WGS") || getenv("HICMI_NNCHAIN_PLAIN") || getenv("HICMI_NNCHAIN_GSIZE")) return -1;
+    if (getenv("HICMI_NNCHAIN_XCD_WIDE")) return xcc;
+    int S = 0, slice = 0; size_t lds = 0;
+    if (!w1_plan(n, 256, NN_W1_MAXS, 0, &S, &slice, &lds)) return -1;
+    return S <= 32 * (int)((160 * 1024) / (lds + 2048)) ? xcc : -1;
 }
 
 // W and W2: two n x ldw buffers (W holds the distances on entry; both are scratch afterwards).
@@ -2302,6 +2385,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     const int w1_cols = w1_cols_text ? (atoi(w1_cols_text) > 64 ? atoi(w1_cols_text) : 64) : 256;
     const int w1_max_s = w1_maxs_text ? atoi(w1_maxs_text) : NN_W1_MAXS;
     const bool dcap_forced = getenv("HICMI_NNCHAIN_DCAP") != nullptr;
+    const bool w1_xcd_wide = getenv("HICMI_NNCHAIN_XCD_WIDE") != nullptr;
     const int gsize_max = (n > NN_MWC_MAX || force_gsize) ? mwc_gsize_max_columns() : 0;
     if (dcap < 1) dcap = 1;
     if (dcap > NN_DMAX) dcap = NN_DMAX;
@@ -2351,7 +2435,22 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
                 const int until = compact ? (n - done) - (int)(((int64_t)n_cur * 3) / 4) : 4096;
                 dcap_e = until > 256 ? until : 256;
             }
-            launch_w1(profile, w1_S, w1_slice, w1_lds, s, cur, ldw, n_cur, chain, zraw, w, dcap_e, total_steps);
+            // all parties on one XCD while they fit there together: 32 CUs x the workgroups a CU's LDS holds
+            int xcc = w1_xcc_env();
+            if (xcc >= 0) {
+                const int per_cu = (int)((160 * 1024) / (w1_lds + 2048));
+                if (w1_S > 32 * per_cu) {
+                    // too many parties for one XCD: spread out as before - or (HICMI_NNCHAIN_XCD_WIDE=1, A/B) fewer, wider slices
+                    int S2 = 0, slice2 = 0; size_t lds2 = 0;
+                    if (w1_xcd_wide && w1_force_s <= 0 && w1_plan(n_cur, w1_cols, 32 * per_cu, 0, &S2, &slice2, &lds2) &&
+                        S2 <= 32 * (int)((160 * 1024) / (lds2 + 2048))) { w1_S = S2; w1_slice = slice2; w1_lds = lds2; }
+                    else xcc = -1;
+                }
+            }
+            // test hook: HICMI_NNCHAIN_TEST_ROLLCALL=k makes epoch k's roll call (1-based) wait for a party that never comes
+            const char* rc_text = getenv("HICMI_NNCHAIN_TEST_ROLLCALL");
+            launch_w1(profile, w1_S, w1_slice, w1_lds, s, cur, ldw, n_cur, chain, zraw, w, dcap_e, total_steps, xcc,
+                      rc_text && atoi(rc_text) == epochs + 1);
             hipLaunchKernelGGL(k_nn_settle, dim3((n_cur + 255) / 256), dim3(256), 0, s, w, n_cur);
             hipLaunchKernelGGL(k_nn_check_hashes, dim3(1), dim3(64), 0, s, w, w1_S);
             flush_needed = false;                                   // it keeps the matrix symmetric itself

@@ -293,9 +293,14 @@ __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
     const double* __restrict__ seq_sum, int n, int P, uint64_t* __restrict__ skeys, uint16_t* __restrict__ sidx,
     uint16_t* __restrict__ R, int64_t ldr, const int32_t* __restrict__ inv, int row_first, int row_stride,
     const int32_t* __restrict__ row_list, int n_list, uint8_t* __restrict__ tie_flag, unsigned* __restrict__ tie_count,
-    unsigned tie_limit, uint16_t* __restrict__ tie_bits, int64_t ld_bits)
+    unsigned tie_limit, uint16_t* __restrict__ tie_bits, int64_t ld_bits, int avoid_xcc, unsigned* __restrict__ row_counter)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_next;
+    // avoid_xcc >= 0 (the pre-sort beside the nn-chain): workgroups that land on that XCD leave at once - the chain's
+    // single-wave workgroups want ALL of its CUs (k_nn_epoch_w1, LOCAL) - and the rows are dealt out by a counter
+    // instead of by block index, so that the others take the whole matrix
+    if (avoid_xcc >= 0 && (int)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 0xfu) == avoid_xcc) return;
     uint64_t* xk = reinterpret_cast<uint64_t*>(smem);                                   // (RB_E / 2) x RB_T keys
     uint16_t* xi = reinterpret_cast<uint16_t*>(smem + (size_t)(RB_E / 2) * RB_T * sizeof(uint64_t));
     const int tile = P < RB_TILE ? P : RB_TILE;            // P >= RB_E (launcher)
@@ -308,7 +313,15 @@ __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
     uint32_t I[RB_E];
 
     const int n_rows = row_list ? n_list : (n - row_first + row_stride - 1) / row_stride;          // this shard's rows
-    for (int it = blockIdx.x; it < n_rows; it += gridDim.x) {
+    auto next_row = [&](int prev) -> int {
+        if (!row_counter) return prev < 0 ? (int)blockIdx.x : prev + (int)gridDim.x;
+        if (threadIdx.x == 0) s_next = (int)atomicAdd(row_counter, 1u);
+        __syncthreads();
+        const int v = s_next;
+        __syncthreads();
+        return v;
+    };
+    for (int it = next_row(-1); it < n_rows; it = next_row(it)) {
         const int row = row_list ? row_list[it] : row_first + it * row_stride;
         // the lane index is re-read through an opaque statement per row: otherwise lane-dependent addresses are hoisted out
         // of the row loop, spilled, and re-loaded / re-stored in every row (1.2 GB of scratch writes per 16k map)
@@ -637,8 +650,11 @@ void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const 
         if (P < RB_E) P = RB_E;
         int wgs = sort_workgroups(n);
         if (max_workgroups > 0 && wgs > max_workgroups) wgs = max_workgroups;
+        if (x.avoid_xcc >= 0 && x.row_counter) wgs = (wgs * 8 + 6) / 7;       // an eighth of the grid leaves at once
+        if (wgs > sort_workgroups(n)) wgs = sort_workgroups(n);               // (the scratch is sized for that many)
         if (x.row_list && wgs > x.n_list) wgs = x.n_list;
         if (wgs < 1) return;
+        const int avoid = x.row_counter ? x.avoid_xcc : -1;
         uint64_t* skeys = reinterpret_cast<uint64_t*>(scratch);
         uint16_t* sidx = reinterpret_cast<uint16_t*>(skeys + (size_t)wgs * (size_t)P);
         const size_t lds = (size_t)(RB_E / 2) * RB_T * (sizeof(uint64_t) + sizeof(uint16_t));
@@ -646,13 +662,13 @@ void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const 
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_rows_rb<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k_sort_rows_rb<true>, dim3(wgs), dim3(RB_T), lds, s, C, ldc, order, np_sum, seq_sum, n, P, skeys,
                                sidx, R, ldr, inv, row_first, row_stride, x.row_list, x.n_list, x.tie_flag, x.tie_count, x.tie_limit,
-                               x.tie_bits, x.ld_bits);
+                               x.tie_bits, x.ld_bits, avoid, x.row_counter);
             return;
         }
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_rows_rb<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_sort_rows_rb<false>, dim3(wgs), dim3(RB_T), lds, s, C, ldc, order, np_sum, seq_sum, n, P, skeys,
                            sidx, R, ldr, inv, row_first, row_stride, x.row_list, x.n_list, (uint8_t*)nullptr, (unsigned*)nullptr, 0u,
-                           (uint16_t*)nullptr, (int64_t)0);
+                           (uint16_t*)nullptr, (int64_t)0, avoid, x.row_counter);
         return;
     }
     const int P = sort_padded_size(n);

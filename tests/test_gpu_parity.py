@@ -162,6 +162,44 @@ def test_upgma_one_wave_per_slice_bit_exact(hic, orc, monkeypatch, n, seed, dcap
     assert np.array_equal(leaves, leaves_o)
 
 
+@pytest.mark.parametrize("xcd", ["off", "5"])
+@pytest.mark.parametrize("n,seed,slices", [(130, 1, 2), (1025, 6, 33), (4099, 8, 64), (4099, 9, 0)])
+def test_upgma_one_wave_per_slice_spread_out_or_on_another_xcd(hic, orc, monkeypatch, n, seed, slices, xcd):
+    """By default the parties of k_nn_epoch_w1 all run on XCD 0 (its LOCAL form: plain stores that stay in that XCD's L2;
+    what the other tests of this kernel exercise).  HICMI_NNCHAIN_XCD=off spreads them over the chip again (sc1 stores,
+    the protocol of rounds 1-2), a digit names another XCD; the linkage is the oracle's either way."""
+    monkeypatch.setenv("HICMI_NNCHAIN_XCD", xcd)
+    if slices:
+        monkeypatch.setenv("HICMI_NNCHAIN_W1_S", str(slices))
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, n)) + 0.01
+    c = c + c.T
+    for _ in range(2):
+        leaves, z, zraw, leaves_o, z_o, zraw_o = _upgma_both(hic, orc, c)
+        assert np.array_equal(zraw, zraw_o)
+        assert np.array_equal(leaves, leaves_o)
+
+
+@pytest.mark.parametrize("epoch", [1, 3])
+def test_upgma_one_wave_roll_call_that_is_never_complete(hic, orc, monkeypatch, epoch):
+    """The parties of a LOCAL epoch first wait until all of them run (a CU of their XCD may be busy with another process's
+    kernels).  Test hook: epoch `epoch` waits for a party that never comes - every party gives up after ~2 ms without having
+    touched anything, the spread-out launch queued behind it runs the epoch, and the rest of the chain stays spread out."""
+    monkeypatch.setenv("HICMI_NNCHAIN_TEST_ROLLCALL", str(epoch))
+    monkeypatch.setenv("HICMI_NNCHAIN_DCAP", "300")
+    rng = np.random.default_rng(31)
+    n = 2100
+    c = rng.random((n, n)) + 0.01
+    c = c + c.T
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(c)
+        leaves, _z = ctx.upgma()
+        assert ctx.nnchain_stats()["retries"] == 0
+        dist = orc.to_distance(c)
+        assert np.array_equal(ctx.raw_merges(), orc.nn_chain_raw(dist))
+        assert np.array_equal(leaves, orc.average_cluster_leaves(dist)[0])
+
+
 @pytest.mark.parametrize("cols", [64, 128, 1024, 2048])
 def test_upgma_one_wave_per_slice_planned_widths(hic, orc, monkeypatch, cols):
     """The plan itself (HICMI_NNCHAIN_W1_COLS columns per slice: 1, 2, 8 or 16 pairs per lane and streamed row) on a Hi-C-like
