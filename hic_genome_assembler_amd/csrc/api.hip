@@ -655,6 +655,12 @@ static int start_presort(hicmi_ctx* c)
         x.row_counter = reinterpret_cast<unsigned*>(c->d_ties) + 1;     // (zeroed with the tie count just above)
         launch_sort_rows(c->dC, c->ldc, c->d_ident, c->d_ident, c->d_np, c->d_seq, (int)n, c->d_sort_scratch, c->dR, ldr, 0, 1,
                          c->stream2, x);
+    }
+    {
+        // (its own family: with the chain's parties holding the LDS of one XCD's CUs, the eighth of this kernel's workgroups
+        //  that is dealt to that XCD - 32 KB of LDS each at 16k - waits for the end of a chain epoch; 0.3 ms of work that
+        //  can read as 8 ms, all of it beside the chain)
+        Timed t(c, F_RANK_INVERT, (2.0 + 2.0) * (double)n * (double)n, c->stream2);
         launch_rank_invert(c->dR, c->dRankS, ldr, (int)n, 0, 1, c->stream2);
     }
     HIPCHK(hipGetLastError());
