@@ -1601,7 +1601,13 @@ __global__ __launch_bounds__(64) void k_nn_epoch_w1(double* __restrict__ W, int6
         if (w1_uni(__hip_atomic_load(&w.state[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return;
         S_ = S_arg; wg_ = slot;
     } else if (xcc_target == -2) {
-        if (w1_uni(__hip_atomic_load(&w.state[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;   // the LOCAL launch did the epoch
+        // the launch behind a LOCAL one: it has nothing to do when that one ran - S_arg slots claimed and nobody gave up.
+        // (Fewer claims than slots: not enough of its workgroups were dealt to the target XCD - placement is not ours to
+        // choose; then nobody may even have noticed, so this launch decides by the count, and the chain stays spread out.)
+        const int gave_up = w1_uni(__hip_atomic_load(&w.state[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int claims = w1_uni(__hip_atomic_load(&w.state[15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (gave_up == 0 && claims >= S_arg) return;
+        if (gave_up == 0 && lane == 0 && blockIdx.x == 0) atomicExch(&w.state[12], 1);
     }
     const int S = S_, wg = wg_;
     const int n4 = (n + 3) & ~3;
@@ -2324,9 +2330,9 @@ static bool w1_plan(int n, int cols, int max_s, int force_s, int* S_out, int* sl
 // beside the chain leaves that XCD alone (api.hip: start_presort), so its 32 CUs are free for up to 64 parties.
 static int w1_xcc_env()
 {
-    const char* t = getenv("HICMI_NNCHAIN_XCD");          // off | 0 .. 7
+    const char* t = getenv("HICMI_NNCHAIN_XCD");          // off | 0 .. 7 (8: an XCD that does not exist - nobody claims a slice; tests)
     if (!t) return 0;
-    return (t[0] < '0' || t[0] > '7') ? -1 : t[0] - '0';
+    return (t[0] < '0' || t[0] > '8') ? -1 : t[0] - '0';
 }
 
 // ... for the pre-sort's benefit: the XCD it should leave alone, i.e. the chain's XCD if the chain's FIRST epoch at n columns

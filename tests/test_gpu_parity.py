@@ -162,12 +162,13 @@ def test_upgma_one_wave_per_slice_bit_exact(hic, orc, monkeypatch, n, seed, dcap
     assert np.array_equal(leaves, leaves_o)
 
 
-@pytest.mark.parametrize("xcd", ["off", "5"])
+@pytest.mark.parametrize("xcd", ["off", "5", "8"])
 @pytest.mark.parametrize("n,seed,slices", [(130, 1, 2), (1025, 6, 33), (4099, 8, 64), (4099, 9, 0)])
 def test_upgma_one_wave_per_slice_spread_out_or_on_another_xcd(hic, orc, monkeypatch, n, seed, slices, xcd):
     """By default the parties of k_nn_epoch_w1 all run on XCD 0 (its LOCAL form: plain stores that stay in that XCD's L2;
     what the other tests of this kernel exercise).  HICMI_NNCHAIN_XCD=off spreads them over the chip again (sc1 stores,
-    the protocol of rounds 1-2), a digit names another XCD; the linkage is the oracle's either way."""
+    the protocol of rounds 1-2), a digit names another XCD - 8 one that does not exist: no workgroup of the LOCAL launch
+    claims a slice and the launch queued behind it sees that from the count; the linkage is the oracle's either way."""
     monkeypatch.setenv("HICMI_NNCHAIN_XCD", xcd)
     if slices:
         monkeypatch.setenv("HICMI_NNCHAIN_W1_S", str(slices))
