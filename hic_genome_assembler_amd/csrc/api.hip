@@ -87,6 +87,7 @@ struct hicmi_ctx {
     int64_t presort_tied_rows = 0;                        // ... and how many rows it re-sorted because they hold equal keys
     int presort_used = 0;                                 // last hicmi_rank_matrix: 0 sorted itself, 1 relabelled the pre-sort, 2 pre-sort discarded (ties)
     int64_t presort_n = 0;                                // > 0: dRankS holds the rows of the current n x n matrix
+    bool presort_dealt = false;                           // its rows were dealt out by a counter (workgroups on the chain's XCD left)
     // cut scan
     int32_t* d_x = nullptr; uint8_t* d_sig = nullptr; int64_t x_cap = 0;
     unsigned char* d_scan_prog = nullptr; int64_t scan_prog_cap = 0;     // device-driven scan loops: state record + lists
@@ -653,6 +654,8 @@ static int start_presort(hicmi_ctx* c)
         x.max_workgroups = 192;                                    // (the chain: up to 64 single-wave workgroups, one CU each)
         x.avoid_xcc = nnchain_local_xcc((int)n);                   // ... all on one XCD, which this kernel's workgroups leave alone
         x.row_counter = reinterpret_cast<unsigned*>(c->d_ties) + 1;     // (zeroed with the tie count just above)
+        if (getenv("HICMI_TEST_PRESORT_ALL_LEAVE")) x.avoid_xcc = -2;      // test hook: every workgroup behaves as if it were on that XCD
+        c->presort_dealt = x.avoid_xcc >= 0 || x.avoid_xcc == -2;
         launch_sort_rows(c->dC, c->ldc, c->d_ident, c->d_ident, c->d_np, c->d_seq, (int)n, c->d_sort_scratch, c->dR, ldr, 0, 1,
                          c->stream2, x);
     }
@@ -846,6 +849,18 @@ int hicmi_rank_matrix(hicmi_ctx* c, const int32_t* order)
         if (rc_up) return rc_up;
     }
     const double share = 1.0 / (double)c->shard_stride;             // this shard's rows only
+    if (c->presort_n == n && bitonic && c->presort_dealt) {
+        // The pre-sort's workgroups that were dealt to the chain's XCD left at once and the others took the rows from a
+        // counter.  Which workgroup runs where is the hardware's business: had ALL of them landed on that XCD, no row
+        // would have been sorted - the counter says how many were handed out.
+        unsigned head[4] = {0, 0, 0, 0};
+        int rc_dl = download(c, head, c->d_ties, sizeof(head));
+        if (rc_dl) return rc_dl;
+        if ((int64_t)head[1] < n) {
+            fprintf(stderr, "[hicmi] pre-sort: only %u of %lld rows were handed out; sorting now\n", head[1], (long long)n);
+            c->presort_n = 0; c->presort_used = 0;
+        }
+    }
     if (c->presort_n == n && bitonic) {
         // rows sorted in storage labels while the nn-chain ran (start_presort): re-addressed by the leaf order; rows that
         // hold equal keys get the order inside their runs from k_rank_rows_tied

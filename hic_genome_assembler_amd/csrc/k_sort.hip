@@ -300,7 +300,7 @@ __global__ __launch_bounds__(RB_T) void k_sort_rows_rb(
     // avoid_xcc >= 0 (the pre-sort beside the nn-chain): workgroups that land on that XCD leave at once - the chain's
     // single-wave workgroups want ALL of its CUs (k_nn_epoch_w1, LOCAL) - and the rows are dealt out by a counter
     // instead of by block index, so that the others take the whole matrix
-    if (avoid_xcc >= 0 && (int)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 0xfu) == avoid_xcc) return;
+    if (avoid_xcc == -2 || (avoid_xcc >= 0 && (int)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 0xfu) == avoid_xcc)) return;   // (-2: test hook)
     uint64_t* xk = reinterpret_cast<uint64_t*>(smem);                                   // (RB_E / 2) x RB_T keys
     uint16_t* xi = reinterpret_cast<uint16_t*>(smem + (size_t)(RB_E / 2) * RB_T * sizeof(uint64_t));
     const int tile = P < RB_TILE ? P : RB_TILE;            // P >= RB_E (launcher)
@@ -650,7 +650,7 @@ void launch_sort_rows(const double* C, int64_t ldc, const int32_t* order, const 
         if (P < RB_E) P = RB_E;
         int wgs = sort_workgroups(n);
         if (max_workgroups > 0 && wgs > max_workgroups) wgs = max_workgroups;
-        if (x.avoid_xcc >= 0 && x.row_counter) wgs = (wgs * 8 + 6) / 7;       // an eighth of the grid leaves at once
+        if (x.avoid_xcc != -1 && x.row_counter) wgs = (wgs * 8 + 6) / 7;      // an eighth of the grid leaves at once
         if (wgs > sort_workgroups(n)) wgs = sort_workgroups(n);               // (the scratch is sized for that many)
         if (x.row_list && wgs > x.n_list) wgs = x.n_list;
         if (wgs < 1) return;

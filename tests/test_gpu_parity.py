@@ -1209,6 +1209,32 @@ def test_rows_sorted_beside_the_chain_equal_rows_sorted_after_it(hic, monkeypatc
         assert len(tied) <= n_tied <= len(tied) + 3 + n // 400
 
 
+def test_rows_sorted_beside_the_chain_when_no_workgroup_takes_a_row(hic, monkeypatch, capfd):
+    """Beside a chain that holds one XCD the pre-sort's workgroups on that XCD leave and the others take the rows from a
+    counter.  Where a workgroup runs is the hardware's choice: if ALL of them left (test hook) no row is sorted - the
+    counter tells, and hicmi_rank_matrix sorts then and there; the rank rows are those of the plain path."""
+    monkeypatch.setenv("HICMI_PRESORT_FROM", "1000")
+    monkeypatch.setenv("HICMI_TEST_PRESORT_ALL_LEAVE", "1")
+    rng = np.random.default_rng(23)
+    n = 2500
+    c = rng.random((n, n)) + 0.01
+    c = np.triu(c) + np.triu(c, 1).T
+    with hic.Context(0) as ctx:
+        ctx.set_contacts(c)
+        leaves, _z = ctx.upgma()
+        ctx.rank_matrix(leaves)
+        assert ctx.presort_state()[0] == 0
+        assert "rows were handed out" in capfd.readouterr().err
+        got = ctx.rank_rows(inverse=True)
+        monkeypatch.delenv("HICMI_TEST_PRESORT_ALL_LEAVE")
+        monkeypatch.setenv("HICMI_NO_PRESORT", "1")
+        ctx.set_contacts(c)
+        leaves2, _z = ctx.upgma()
+        ctx.rank_matrix(leaves2)
+        want = ctx.rank_rows(inverse=True)
+    assert np.array_equal(leaves, leaves2) and np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("n", [3000, 20000, 40000])        # 16 / 32 / 64 elements per lane
 def test_rank_rows_with_short_runs_of_equal_similarities(hic, monkeypatch, n):
     """fp32-valued contacts give every row a few collisions; such rows are finished by k_rank_rows_short_runs (two rounds of
