@@ -153,10 +153,14 @@ def averageClusterNodes(adjacencyMatrix: DeviceMatrix, nodeLabels, noPlot=True, 
     return {"ivl": [nodeLabels[i] for i in leaves], "leaves": leaves, "Z": z}
 
 
-def dendrogramLeafOrder_toFile(dendrogramObj, outFile):
-    """S2C:210-220: ``label<TAB>leaf`` lines, no trailing newline."""
+def dendrogramLeafOrder_toFile(dendrogramObj, outFile, lines=None):
+    """S2C:210-220: ``label<TAB>leaf`` lines, no trailing newline.  ``lines``: the line of every leaf, indexed by leaf
+    (formatted beside the chain: runResident)."""
     with open(outFile, "w") as fh:
-        fh.write("\n".join(l + "\t" + str(i) for l, i in zip(dendrogramObj["ivl"], dendrogramObj["leaves"])))
+        if lines is not None:
+            fh.write("\n".join(map(lines.__getitem__, dendrogramObj["leaves"])))
+        else:
+            fh.write("\n".join(l + "\t" + str(i) for l, i in zip(dendrogramObj["ivl"], dendrogramObj["leaves"])))
 
 
 def readDengrogramLeavesFromFile(dendrogramFile):
@@ -355,15 +359,24 @@ def filter_noisy_breakpoints(argsorted_mat: RankMatrix, original_inds, psig=.05)
 
 
 # ------------------------------------------------------------------------------------------------
-def writeBinGroupingsToFile(coords, binList, outFile):
+def _bin_line(b):
+    return f"{b.ID}\t{b.chrom}\t{b.start}\t{b.stop}\t{b.bias}"
+
+
+def writeBinGroupingsToFile(coords, binList, outFile, bin_lines=None):
     """S2C:945-964.  Returns the groups as lists of the lines written (what
-    readBinGroupingsFromFile gives back for this file)."""
+    readBinGroupingsFromFile gives back for this file).  ``bin_lines``: {bin ID: its line} when the caller has formatted
+    them already (runResident does, beside the chain)."""
     bounds = [0] + [int(c) for c in coords] + [len(binList)]
     groups, text = [], []
     for g in range(len(bounds) - 1):
-        lines = [f"{b.ID}\t{b.chrom}\t{b.start}\t{b.stop}\t{b.bias}" for b in binList[bounds[g]:bounds[g + 1]]]
+        if bin_lines is not None:
+            lines = [bin_lines[b.ID] for b in binList[bounds[g]:bounds[g + 1]]]
+        else:
+            lines = [_bin_line(b) for b in binList[bounds[g]:bounds[g + 1]]]
         text.append("### Chromosome group " + str(g + 1) + " ###\n")
-        text.extend(l + "\n" for l in lines)
+        if lines:
+            text.append("\n".join(lines) + "\n")
         groups.append(lines)
     with open(outFile, "w") as fh:
         fh.write("".join(text))
@@ -503,12 +516,16 @@ def rankChromosomeGroups(chromList, scaffSizeDict):
     return [chromList[k] for k in ranked]
 
 
-def writeChromosomeGroupingsToFile(chromList, scaffSizeDict, outFile):
-    """S2C:1079-1100: groups ordered by total scaffold bp, largest first (stable)."""
+def writeChromosomeGroupingsToFile(chromList, scaffSizeDict, outFile, entry_lines=None):
+    """S2C:1079-1100: groups ordered by total scaffold bp, largest first (stable).  ``entry_lines``: {bin ID: its
+    ``bin<TAB>scaffold`` line with the newline} when formatted already."""
     text = []
     for new_id, grp in enumerate(rankChromosomeGroups(chromList, scaffSizeDict)):
         text.append("### Chromosome group " + str(new_id + 1) + " ###\n")
-        text.extend(str(e[0]) + "\t" + str(e[1]) + "\n" for e in grp)
+        if entry_lines is not None:
+            text.extend([entry_lines[e[0]] for e in grp])
+        else:
+            text.extend(str(e[0]) + "\t" + str(e[1]) + "\n" for e in grp)
     with open(outFile, "w") as fh:
         fh.write("".join(text))
 
@@ -632,6 +649,11 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
             prep["sizes"] = readSizeFileToDict(hicProScaffSizeFile)
             prep["scaffolds"] = _scaffold_bins((b.ID, b.chrom) for b in bl)
             prep["pairs"] = _bin_pairs(bl)
+            # the text of the three per-bin files, line by line: ~12 ms of formatting at 16k that would otherwise hold the
+            # interpreter lock while Part 2's threads want it (the writer thread only joins the lines)
+            prep["dend_lines"] = [lab + "\t" + str(i) for i, lab in enumerate(prep["labels"])]
+            prep["bin_lines"] = {b.ID: _bin_line(b) for b in bl}
+            prep["entry_lines"] = {int(b.ID): str(int(b.ID)) + "\t" + str(b.chrom) + "\n" for b in bl}
         dendrogram = averageClusterNodes(adjMat, lambda: prep["labels"], noPlot=True, meanwhile=meanwhile)
         mark("UPGMA + leaf order")
         # the reference parses the file back (readDengrogramLeavesFromFile); the leaves are the same integers
@@ -642,7 +664,7 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
         argsorted_adjMat = rankOrderMatrix(adjMat)
         # the dendrogram file (16k formatted lines: ~5 ms of interpreter time) is handed to the writer thread only now: the
         # two scan loops that follow are native calls that release the interpreter lock, the list work above is not
-        writer.submit(dendrogramLeafOrder_toFile, dendrogram, dendrogramOrderFile)
+        writer.submit(dendrogramLeafOrder_toFile, dendrogram, dendrogramOrderFile, prep["dend_lines"])
         mark("reorder + rank matrix")
         initial_cut_inds = pre_process_all_matrix_breakpoints(argsorted_adjMat, min_size=minSize,
                                                               min_frac=modularity, psig=psig)
@@ -659,7 +681,7 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
                 new_order, cutIndices = louvain.modularity_remaining_data(louvain.log_transform(sim_tail), binList,
                                                                           cutIndices, n_rounds=louvainRounds)
                 adjMat, binList = reorderMatrix(adjMat, binList, new_order)
-        writer.submit(writeBinGroupingsToFile, list(cutIndices), list(binList), binGroupFile, deferred=True)
+        writer.submit(writeBinGroupingsToFile, list(cutIndices), list(binList), binGroupFile, prep["bin_lines"], deferred=True)
         binGroups = _bin_group_pairs(cutIndices, binList, prep["pairs"])
         print("Total run-time to identify chromosome boundaries = " + str(time.time() - t0))
         t0 = time.time()
@@ -669,7 +691,8 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
                                                write=lambda fn, *a: writer.submit(fn, *a, deferred=True),
                                                scaffolds=None if (modularity is not False and modularity > 0.0) else prep["scaffolds"])
         adjMat.chromosome_groups = rankChromosomeGroups(chrGroups, fastaSizeDict)
-        writer.submit(writeChromosomeGroupingsToFile, chrGroups, fastaSizeDict, chromosomeGroupFile, deferred=True)
+        writer.submit(writeChromosomeGroupingsToFile, chrGroups, fastaSizeDict, chromosomeGroupFile, prep["entry_lines"],
+                      deferred=True)
         print("Total run-time to assign scaffolds to chromosomes = " + str(time.time() - t0))
         mark("groups + assessment")
     if not overlap_files:
