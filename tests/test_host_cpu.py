@@ -242,6 +242,45 @@ def test_intermediate_files_round_trip(tmp_path):
     report = open(tmp_path / "a.txt").read()
     assert "scaf1\t2\t7\t28.57%" in report and "scaf1\t5\t7\t71.43%" in report
     assert "Falsely clustered nodes 4" in report
+    # the pre-formatted forms runResident hands to the writer thread give the same bytes as formatting in the writers
+    labels = [b.chrom + "_" + str(b.ID) for b in bins]
+    s2c.dendrogramLeafOrder_toFile({"ivl": [labels[i] for i in dend["leaves"]], "leaves": dend["leaves"]}, str(tmp_path / "d3.txt"))
+    s2c.dendrogramLeafOrder_toFile({"ivl": None, "leaves": dend["leaves"]}, str(tmp_path / "d4.txt"),
+                                   [lab + "\t" + str(i) for i, lab in enumerate(labels)])
+    assert open(tmp_path / "d3.txt").read() == open(tmp_path / "d4.txt").read()
+    s2c.writeBinGroupingsToFile([9, 30], bins, str(tmp_path / "g2.txt"), {b.ID: s2c._bin_line(b) for b in bins})
+    assert open(tmp_path / "g.txt").read() == open(tmp_path / "g2.txt").read()
+    s2c.writeChromosomeGroupingsToFile(final, sizes, str(tmp_path / "c2.txt"),
+                                       {int(b.ID): str(int(b.ID)) + "\t" + str(b.chrom) + "\n" for b in bins})
+    assert open(tmp_path / "c.txt").read() == open(tmp_path / "c2.txt").read()
+
+
+def test_part2_file_text_by_pieces(tmp_path):
+    """orderGenome formats each chromosome's share of the two output files on its scan thread; written from those pieces
+    the files are byte for byte what the writers produce from the scaffold lists."""
+    from hic_genome_assembler_amd import orderGenome as og
+    import contextlib, io
+    groups, k = [], 0
+    for c in range(3):
+        g = []
+        for i in range(4 + c):
+            sc = og.Scaffold("s%d_%d" % (c, i), list(range(k, k + 1 + (i % 3))), "-" if (i + c) % 2 else "+")
+            k += len(sc.binList)
+            g.append(sc)
+        groups.append(g)
+    groups.append([og.Scaffold("empty", [], "+")])
+    flat = [s for g in groups for s in g]
+    with contextlib.redirect_stdout(io.StringIO()) as out_a:
+        og.writeScaffoldOrderingsToFile(groups, str(tmp_path / "o1.txt"))
+        og.writeBinIDsOrderingToFile(flat, str(tmp_path / "p1.txt"))
+    with contextlib.redirect_stdout(io.StringIO()) as out_b:
+        og.writeScaffoldOrderingsToFile(groups, str(tmp_path / "o2.txt"), [og._scaffold_lines(g) for g in groups])
+        og.writeBinIDsOrderingToFile(flat, str(tmp_path / "p2.txt"), [og._bin_rows(g) for g in groups])
+    assert open(tmp_path / "o1.txt").read() == open(tmp_path / "o2.txt").read()
+    assert open(tmp_path / "p1.txt").read() == open(tmp_path / "p2.txt").read()
+    assert out_a.getvalue() == out_b.getvalue()
+    text = open(tmp_path / "p1.txt").read()
+    assert text.startswith("#ScaffoldID\tHiCPro-BinID\ns0_0\t0") and not text.endswith("\n")
 
 
 def test_matrix_binary_cache(tmp_path):
