@@ -2377,6 +2377,18 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     // of their own.  Worth 1.5 ms per 16k map (scans per merge 1.28 -> 1.23: most such rows are walked within the epoch that
     // invalidated them); above ~12,000 columns the pass costs more than the scans it saves.  0 = never.
     const int refresh_below = 8000;
+    // The matrix is compacted - live rows and columns copied into the other buffer - when HALF of its columns have merged
+    // away.  (Rounds 1-2 and the first one-wave kernel compacted at three quarters: with deferred column writes a merge's
+    // cost grew with the width.  The one-wave kernel's does not until the slice drops under the next power-of-two number of
+    // pairs per lane, an epoch boundary costs ~100 us plus the copy, and a 32k map is down to one XCD's capacity after ONE
+    // compaction instead of two.  Measured on one box, 3/4 | 2/3 | 3/5 | 1/2 | 2/5 | 1/3 | 1/4 of the columns left:
+    // 16k 81.6 | 80.4 | 80.1 | 80.0 | 80.3 | 80.5 | 80.8 ms, 32k 203.5 | 197.6 | 200.2 | 194.0 | 198.3 | 202.4 | 206.0 ms;
+    // 64k 602.7 -> 586.6 ms.)  HICMI_NNCHAIN_COMPACT_AT=<num>/<den> sets another fraction (A/B).
+    int cnum = 1, cden = 2;
+    if (const char* t = getenv("HICMI_NNCHAIN_COMPACT_AT")) {
+        int a = 0, b = 0;
+        if (sscanf(t, "%d/%d", &a, &b) == 2 && a >= 1 && b > a && b <= 64) { cnum = a; cden = b; }
+    }
     const bool force_gsize = getenv("HICMI_NNCHAIN_GSIZE") != nullptr;   // the GSIZE variant of k_nn_epoch_mwc at every width (tests)
     // One wave per column slice (k_nn_epoch_w1): the default at every width up to 32,768 live columns.  HICMI_NNCHAIN_W1=0
     // selects the 1024-lane kernels of rounds 1-2 instead (A/B; so does every switch that names one of them);
@@ -2436,9 +2448,9 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
             if (!cache_valid || (refresh_below > 0 && n_cur <= refresh_below)) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
             cache_valid = true;
             // the one-wave kernel renormalises its time stamps itself: an epoch runs until the next compaction is due
-            // (a quarter of the live columns have merged away), at least 256 merges; HICMI_NNCHAIN_DCAP still forces a length
+            // (half of the columns have merged away), at least 256 merges; HICMI_NNCHAIN_DCAP still forces a length
             if (!dcap_forced) {
-                const int until = compact ? (n - done) - (int)(((int64_t)n_cur * 3) / 4) : 4096;
+                const int until = compact ? (n - done) - (int)(((int64_t)n_cur * cnum) / cden) : 4096;
                 dcap_e = until > 256 ? until : 256;
             }
             // all parties on one XCD while they fit there together: 32 CUs x the workgroups a CU's LDS holds
@@ -2488,7 +2500,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
         if (done >= total_steps) break;
         if (flush_needed) hipLaunchKernelGGL(k_nn_flush, dim3((n_cur + 255) / 256, dcap), dim3(256), 0, s, cur, ldw, n_cur, w);
         const int live = n - done;
-        if (compact && other && live >= 2 && (int64_t)live * 4 <= (int64_t)n_cur * 3) {
+        if (compact && other && live >= 2 && (int64_t)live * cden <= (int64_t)n_cur * cnum) {
             hipLaunchKernelGGL(k_nn_translate, dim3((done - interval_start + 255) / 256), dim3(256), 0, s, zraw, interval_start,
                                done, w);
             interval_start = done;
