@@ -1463,6 +1463,10 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_epoch_mwc(double* __restrict_
 // matrix byte, stores drained before the mailbox store, bounded spins, double-buffered 16-byte slots that carry their
 // sequence number in both halves).
 static constexpr int NN_W1_DCAP = 252;                   // merges per epoch: 8-bit times
+// columns per slice the plan aims at (the 64 parties stay until 8,192 columns are left).  Swept with the parties on one XCD,
+// 64 | 96 | 128 | 160 | 192 | 256 | 320: 16k 78.3 | 78.3 | 78.0 | 80.1 | 80.2 | 79.8 | 96.3 ms, 32k 199.0 | 197.9 | 192.6 | 194.7 | 195.4 |
+// 194.3 | 216.7 ms, 2k 8.2 | 8.1 | 8.1 | 8.8 | - | 9.0 | - ms (round 3's first plan was 256: spread out, an exchange cost twice as much)
+static constexpr int NN_W1_COLS = 128;
 static constexpr int NN_W1_MAX = 32767;                  // 15-bit slot numbers; one 4-byte word per column in the LDS of every replica
 static constexpr uint32_t W1_NOIDX = 0x7fffu;
 // Loads of this kernel are COMPILER-VISIBLE (its wait-count pass tracks them): the streamed pairs are raw buffer loads with
@@ -2346,7 +2350,7 @@ int nnchain_local_xcc(int n)
     if ((w1_text && atoi(w1_text) == 0) || getenv("HICMI_NNCHAIN_WGS") || getenv("HICMI_NNCHAIN_PLAIN") || getenv("HICMI_NNCHAIN_GSIZE")) return -1;
     if (getenv("HICMI_NNCHAIN_XCD_WIDE")) return xcc;
     int S = 0, slice = 0; size_t lds = 0;
-    if (!w1_plan(n, 256, NN_W1_MAXS, 0, &S, &slice, &lds)) return -1;
+    if (!w1_plan(n, NN_W1_COLS, NN_W1_MAXS, 0, &S, &slice, &lds)) return -1;
     return S <= 32 * (int)((160 * 1024) / (lds + 2048)) ? xcc : -1;
 }
 
@@ -2400,7 +2404,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     const char* w1_maxs_text = getenv("HICMI_NNCHAIN_W1_MAXS");
     const bool w1_on = !(w1_text && atoi(w1_text) == 0) && !wgs_text && !force_single && !plain && !force_gsize;
     const int w1_force_s = w1_s_text ? atoi(w1_s_text) : 0;
-    const int w1_cols = w1_cols_text ? (atoi(w1_cols_text) > 64 ? atoi(w1_cols_text) : 64) : 256;
+    const int w1_cols = w1_cols_text ? (atoi(w1_cols_text) > 64 ? atoi(w1_cols_text) : 64) : NN_W1_COLS;
     const int w1_max_s = w1_maxs_text ? atoi(w1_maxs_text) : NN_W1_MAXS;
     const bool dcap_forced = getenv("HICMI_NNCHAIN_DCAP") != nullptr;
     const bool w1_xcd_wide = getenv("HICMI_NNCHAIN_XCD_WIDE") != nullptr;

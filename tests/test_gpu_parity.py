@@ -201,7 +201,7 @@ def test_upgma_one_wave_roll_call_that_is_never_complete(hic, orc, monkeypatch, 
         assert np.array_equal(leaves, orc.average_cluster_leaves(dist)[0])
 
 
-@pytest.mark.parametrize("cols", [64, 128, 1024, 2048])
+@pytest.mark.parametrize("cols", [64, 256, 1024, 2048])
 def test_upgma_one_wave_per_slice_planned_widths(hic, orc, monkeypatch, cols):
     """The plan itself (HICMI_NNCHAIN_W1_COLS columns per slice: 1, 2, 8 or 16 pairs per lane and streamed row) on a Hi-C-like
     map with planted chromosomes and on its quantised, sparse twin (exact ties in every row: the cache must defer to scans)."""
