@@ -716,11 +716,11 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
     // from 124.8 to 118.0 ms at 16k and from 282.5 to 272.4 ms at 32k (128: no further gain - ~40 us of launches per epoch)
     const char* cap = getenv("HICMI_NNCHAIN_DCAP");
     struct { int state[16]; unsigned long long prof[8]; unsigned char mail[1152]; unsigned long long detail[32]; } nn;   // the head of the workspace
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = 0; attempt < 3; attempt++) {
         {
             Timed t(c, F_NNCHAIN, 0.0);
             int epochs = launch_nnchain(c->dW, c->dW2, ldw, (int)n, c->d_chain, c->d_zraw, c->d_size, prof_on,
-                                        cap ? atoi(cap) : 256, getenv("HICMI_NNCHAIN_NO_COMPACT") == nullptr, attempt > 0, c->stream);
+                                        cap ? atoi(cap) : 256, getenv("HICMI_NNCHAIN_NO_COMPACT") == nullptr, attempt, c->stream);
             // the family is reported per epoch launch (the flush / compaction launches in between are ~1 % of it)
             if (epochs > 1) c->launches[F_NNCHAIN] += epochs - 1;
         }
@@ -730,11 +730,13 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         c->bytes[F_NNCHAIN] += 8.0 * ((double)nn.prof[5] + 3.0 * (0.5 * (double)(n - 1) * (double)(n + 2)));
         c->nn_scans += (double)nn.prof[6]; c->nn_scan_cols += (double)nn.prof[5]; c->nn_cache_hits += (double)nn.prof[7];
         c->nn_merges += (double)(n - 1);
-        if (nn.state[5] != 2 || attempt > 0) break;
+        if (nn.state[5] != 2 || attempt > 1) break;
         // A peer workgroup of the column-sliced chain did not answer within its spin budget (a GPU shared with other
         // work can delay a workgroup's start): nothing is wrong with the data.  Rebuild the distances and run the whole
-        // chain again on one workgroup, which waits for nobody.
-        fprintf(stderr, "[hicmi] nn-chain: a peer workgroup answered late at merge %d; re-running on one workgroup\n", nn.state[0]);
+        // chain again - spread over the chip first (had its parties asked for one XCD), then on one workgroup, which
+        // waits for nobody.
+        fprintf(stderr, "[hicmi] nn-chain: a peer workgroup answered late at merge %d; re-running %s\n", nn.state[0],
+                attempt == 0 ? "with the parties spread over the chip" : "on one workgroup");
         c->nn_retries++;
         launch_build_w(c->dC, c->ldc, c->d_np, (int)n, c->dW, ldw, c->stream);
         HIPCHK(hipGetLastError());

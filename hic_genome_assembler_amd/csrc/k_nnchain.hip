@@ -2357,8 +2357,11 @@ int nnchain_local_xcc(int n)
 // W and W2: two n x ldw buffers (W holds the distances on entry; both are scratch afterwards).
 // Returns the number of epoch launches.  force_single: never the column-sliced kernel (the retry after a late peer).
 int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double* zraw, void* workspace, bool profile,
-                   int dcap, bool compact, bool force_single, hipStream_t s)
+                   int dcap, bool compact, int fallback, hipStream_t s)
 {
+    // fallback (the retries after "a peer answered late"): 1 = the one-wave kernel spread over the chip, never on one XCD;
+    // 2 = one workgroup, which waits for nobody
+    const bool force_single = fallback >= 2;
     int epochs = 0;
     NNWorkspace w = carve(workspace, n);
     // Column-sliced chain on several workgroups (k_nn_epoch_mw): its fixed cost per scan (one exchange) is paid back
@@ -2417,7 +2420,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     {
         static int hooks[2];                                     // test hooks: see NNWorkspace::state[10], [11]
         const char* a = getenv("HICMI_NNCHAIN_TEST_LATE"); const char* b = getenv("HICMI_NNCHAIN_TEST_DIVERGE");
-        hooks[0] = (a && !force_single) ? atoi(a) : 0; hooks[1] = b ? atoi(b) : 0;
+        hooks[0] = (a && fallback == 0) ? atoi(a) : 0; hooks[1] = b ? atoi(b) : 0;      // (the retries run without the late-peer hook)
         if (hooks[0] || hooks[1]) hipMemcpyAsync(w.state + 10, hooks, sizeof(hooks), hipMemcpyHostToDevice, s);
     }
     const int total_steps = n - 1;
@@ -2458,7 +2461,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
                 dcap_e = until > 256 ? until : 256;
             }
             // all parties on one XCD while they fit there together: 32 CUs x the workgroups a CU's LDS holds
-            int xcc = w1_xcc_env();
+            int xcc = (fallback >= 1 ? -1 : w1_xcc_env());
             if (xcc >= 0) {
                 const int per_cu = (int)((160 * 1024) / (w1_lds + 2048));
                 if (w1_S > 32 * per_cu) {

@@ -220,7 +220,8 @@ def test_upgma_one_wave_per_slice_planned_widths(hic, orc, monkeypatch, cols):
 
 
 def test_upgma_one_wave_per_slice_late_peer_and_divergence(hic, orc, monkeypatch, capfd):
-    """The safety nets on the one-wave kernel: an exchange declared late (test hook) re-runs the map on one workgroup;
+    """The safety nets on the one-wave kernel: an exchange declared late (test hook) re-runs the map - spread over the chip first, on one
+    workgroup if that is late too;
     a replica whose merge record differs (test hook: replica 1 flips a bit of the height of merge 123 in its hash) fails the
     call instead of returning a tree."""
     monkeypatch.setenv("HICMI_NNCHAIN_W1_S", "5")
@@ -361,7 +362,8 @@ def test_upgma_neighbour_cache_counters(hic, orc):
 
 def test_upgma_late_peer_falls_back_to_one_workgroup(hic, orc, monkeypatch, capfd):
     """A peer workgroup of the column-sliced chain that does not answer in time (test hook: the 40th exchange is
-    declared late) must not fail the map: the distances are rebuilt and the chain re-runs on one workgroup."""
+    declared late) must not fail the map: the distances are rebuilt and the chain re-runs (without the one-XCD form first,
+    then on one workgroup)."""
     monkeypatch.setenv("HICMI_NNCHAIN_WGS", "4")
     monkeypatch.setenv("HICMI_NNCHAIN_TEST_LATE", "40")
     rng = np.random.default_rng(12)
