@@ -73,7 +73,7 @@ class ChromosomeLayout:
             self.names.append(s.name)
             self.start.append(pos)
             self.length.append(len(bins))
-            sel += [where[b] for b in bins]
+            sel.extend(map(where.__getitem__, bins))
             pos += len(bins)
         self.n = pos
         self.ctx.p2_select(sel)
@@ -246,14 +246,16 @@ class Scaffold:
 def initiateBinsAndScaffolds(nodeList):
     """OG:256-280: scaffolds in order of first appearance, bins ascending, then a stable sort by
     bin count, largest first."""
-    scaffDict = {}
+    bins_of = {}
     for bin_id, name in nodeList:
-        if name not in scaffDict:
-            scaffDict[name] = Scaffold(name, [], "+")
-        scaffDict[name].binList.append(bin_id)
+        b = bins_of.get(name)
+        if b is None:
+            bins_of[name] = [bin_id]
+        else:
+            b.append(bin_id)
+    scaffDict = {name: Scaffold(name, sorted(b), "+") for name, b in bins_of.items()}      # (order of first appearance)
     print("Scaffolds to order for this chromosome " + str(len(scaffDict)))
     for s in scaffDict.values():
-        s.binList = sorted(s.binList)
         s.nodeCount = len(s.binList)
     scaffList = sorted(scaffDict.values(), key=lambda s: len(s.binList), reverse=True)
     return scaffList, scaffDict
