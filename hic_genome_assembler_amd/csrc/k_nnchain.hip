@@ -2332,10 +2332,42 @@ static bool w1_plan(int n, int cols, int max_s, int force_s, int* S_out, int* sl
 
 // The XCD the one-wave kernel claims (its LOCAL form), or -1: HICMI_NNCHAIN_XCD=off | 0..7 (default 0).  The pre-sort that runs
 // beside the chain leaves that XCD alone (api.hip: start_presort), so its 32 CUs are free for up to 64 parties.
+// Which XCC ids this device's workgroups report at all: the lowest is the default target.  (A whole MI355X answers 0 ... 7; a
+// partition of one may answer with a single id, and not necessarily 0 - a fixed target would then never be claimed.)
+__global__ void k_probe_xcc(int* __restrict__ out)
+{
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 0xfu);
+}
+
+static int w1_probed_xcc()
+{
+    static std::atomic<int> cached[64];
+    static std::atomic<bool> init{false};
+    if (!init.exchange(true)) for (auto& c : cached) c.store(-2);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int v = cached[dev].load();
+    if (v != -2) return v;
+    v = 0;
+    int* d = nullptr;
+    if (hipMalloc((void**)&d, 256 * sizeof(int)) == hipSuccess) {
+        int h[256];
+        hipLaunchKernelGGL(k_probe_xcc, dim3(256), dim3(64), 0, 0, d);
+        if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            v = 15;
+            for (int i = 0; i < 256; i++) if (h[i] >= 0 && h[i] < v) v = h[i];
+            if (v > 7) v = 0;
+        }
+        (void)hipFree(d);
+    }
+    cached[dev].store(v);
+    return v;
+}
+
 static int w1_xcc_env()
 {
     const char* t = getenv("HICMI_NNCHAIN_XCD");          // off | 0 .. 7 (8: an XCD that does not exist - nobody claims a slice; tests)
-    if (!t) return 0;
+    if (!t) return w1_probed_xcc();
     return (t[0] < '0' || t[0] > '8') ? -1 : t[0] - '0';
 }
 
