@@ -704,9 +704,13 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         launch_build_w(c->dC, c->ldc, c->d_np, (int)n, c->dW, ldw, c->stream);
     }
     HIPCHK(hipGetLastError());
-    rc = start_presort(c);                                         // beside the chain, on the second stream
-    if (rc) return rc;
-    mark("build_w + pre-sort queued");
+    // The pre-sort runs beside the chain on the second stream - from the moment the chain's FIRST cache pass (k_nn_rowmin over
+    // the whole matrix, the one full-chip pass the chain has) is queued: started right after k_build_w the pre-sort's 192
+    // big workgroups shared the CUs with that pass and stretched it from 0.5 to 2.4 ms at 16k, from 2 to 9.8 ms at 32k.
+    int presort_rc = HICMI_OK;
+    bool presort_started = false;
+    auto presort_now = [&] { if (!presort_started) { presort_started = true; presort_rc = start_presort(c); } };
+    mark("build_w queued");
     // The nn-chain.  Algorithmic bytes: 8 B x (sum over row scans of the live columns + 3 x sum over merges
     // of the live columns), with the scans counted by the kernels themselves (a scan the neighbour cache answers moves
     // nothing); the merge term is 3 * 8 * sum_{k=0}^{n-2} (n - k).
@@ -720,7 +724,10 @@ int hicmi_upgma(hicmi_ctx* c, double* Z_out, int32_t* leaves_out)
         {
             Timed t(c, F_NNCHAIN, 0.0);
             int epochs = launch_nnchain(c->dW, c->dW2, ldw, (int)n, c->d_chain, c->d_zraw, c->d_size, prof_on,
-                                        cap ? atoi(cap) : 256, getenv("HICMI_NNCHAIN_NO_COMPACT") == nullptr, attempt, c->stream);
+                                        cap ? atoi(cap) : 256, getenv("HICMI_NNCHAIN_NO_COMPACT") == nullptr, attempt, c->stream,
+                                        presort_now);
+            presort_now();                                         // (whatever path the chain took)
+            if (presort_rc) return presort_rc;
             // the family is reported per epoch launch (the flush / compaction launches in between are ~1 % of it)
             if (epochs > 1) c->launches[F_NNCHAIN] += epochs - 1;
         }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <functional>
 
 namespace hicmi {
 
@@ -125,7 +126,9 @@ void launch_build_w(const double* C, int64_t ldc, const double* np_sum, int n, d
 // k_nnchain.hip
 size_t nnchain_workspace_bytes(int n);
 int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double* zraw, void* workspace, bool profile,
-                   int dcap, bool compact, int fallback, hipStream_t s);   // returns the number of epoch launches; fallback: 0, 1 (spread out), 2 (one workgroup)
+                   int dcap, bool compact, int fallback, hipStream_t s, const std::function<void()>& after_first_rowmin = nullptr);
+                                              // returns the number of epoch launches; fallback: 0, 1 (spread out), 2 (one workgroup);
+                                              // after_first_rowmin: called once, when the first epoch's cache pass is queued
 void launch_selftest_division(unsigned long long seed, int blocks, int iters, unsigned long long* d_mismatches, hipStream_t s);
 const int* nnchain_state_ptr(void* workspace);                    // 16 ints: [0] merges done ... [5] stop code (0 = none,
                                                                   // 1 = guard / NaN, 2 = a peer workgroup answered late, 3 = replicas disagree)

@@ -2389,8 +2389,10 @@ int nnchain_local_xcc(int n)
 // W and W2: two n x ldw buffers (W holds the distances on entry; both are scratch afterwards).
 // Returns the number of epoch launches.  force_single: never the column-sliced kernel (the retry after a late peer).
 int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double* zraw, void* workspace, bool profile,
-                   int dcap, bool compact, int fallback, hipStream_t s)
+                   int dcap, bool compact, int fallback, hipStream_t s, const std::function<void()>& after_first_rowmin)
 {
+    bool told = false;
+    auto tell = [&] { if (!told && after_first_rowmin) after_first_rowmin(); told = true; };
     // fallback (the retries after "a peer answered late"): 1 = the one-wave kernel spread over the chip, never on one XCD;
     // 2 = one workgroup, which waits for nobody
     const bool force_single = fallback >= 2;
@@ -2486,6 +2488,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
         if (w1_on && w1_plan(n_cur, w1_cols, w1_max_s, w1_force_s, &w1_S, &w1_slice, &w1_lds)) {
             if (!cache_valid || (refresh_below > 0 && n_cur <= refresh_below)) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
             cache_valid = true;
+            tell();
             // the one-wave kernel renormalises its time stamps itself: an epoch runs until the next compaction is due
             // (half of the columns have merged away), at least 256 merges; HICMI_NNCHAIN_DCAP still forces a length
             if (!dcap_forced) {
@@ -2516,6 +2519,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
             // column slices + neighbour cache + the next scan fused into the update (k_nn_epoch_mwc)
             if (!cache_valid || (refresh_below > 0 && n_cur <= refresh_below)) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
             cache_valid = true;
+            tell();
             const size_t lds_c = align16((size_t)nw4 * 12 + (size_t)((n_cur + 7) & ~7) * (gsize ? 2 : 4));
             hipMemsetAsync(reinterpret_cast<unsigned char*>(w.state) + 128, 0, 1152, s);      // mailboxes
             launch_mwc(wgs_e, profile, lds_c, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps, gsize);
@@ -2524,11 +2528,13 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
         else if (!plain && n_cur <= NN_NC_MAX) {
             if (!cache_valid || (refresh_below > 0 && n_cur <= refresh_below)) hipLaunchKernelGGL(k_nn_rowmin, dim3(n_cur), dim3(256), 0, s, cur, ldw, n_cur, w);
             cache_valid = true;
+            tell();
             const size_t lds_nc = align16((size_t)nw4 * 12 + (size_t)((n_cur + 7) & ~7) * 4);
             if (profile) hipLaunchKernelGGL(k_nn_epoch_nc<true>, dim3(1), dim3(NN_THREADS), lds_nc, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
             else hipLaunchKernelGGL(k_nn_epoch_nc<false>, dim3(1), dim3(NN_THREADS), lds_nc, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
         }
         else {
+            tell();
             if (profile) hipLaunchKernelGGL(k_nn_epoch<true>, dim3(1), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
             else hipLaunchKernelGGL(k_nn_epoch<false>, dim3(1), dim3(NN_THREADS), lds, s, cur, ldw, n_cur, chain, zraw, w, dcap, total_steps);
             cache_valid = false;
@@ -2551,6 +2557,7 @@ int launch_nnchain(double* W, double* W2, int64_t ldw, int n, int* chain, double
     }
     hipLaunchKernelGGL(k_nn_translate, dim3((total_steps - interval_start + 255) / 256), dim3(256), 0, s, zraw, interval_start,
                        total_steps, w);
+    tell();
     return epochs;
 }
 
