@@ -519,10 +519,14 @@ int hicmi_label_linkage(const double* zraw, int64_t n, double* Z)
 {
     if (!zraw || !Z || n < 1) return fail(HICMI_EINVAL, "bad arguments");
     const int64_t m = n - 1;
+    // numpy argsort(kind='mergesort') on the heights: stable.  (height, index) pairs side by side: the comparator of an
+    // index sort fetched two scattered heights per comparison - 1.1 ms at 16k bins, 6.3 ms at 64k
+    std::vector<std::pair<double, int64_t>> keyed((size_t)m);
+    for (int64_t i = 0; i < m; i++) keyed[(size_t)i] = {zraw[4 * i + 2], i};
+    std::stable_sort(keyed.begin(), keyed.end(),
+                     [](const std::pair<double, int64_t>& x, const std::pair<double, int64_t>& y) { return x.first < y.first; });
     std::vector<int64_t> idx((size_t)m);
-    std::iota(idx.begin(), idx.end(), (int64_t)0);
-    // numpy argsort(kind='mergesort') on the heights: stable
-    std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return zraw[4 * a + 2] < zraw[4 * b + 2]; });
+    for (int64_t i = 0; i < m; i++) idx[(size_t)i] = keyed[(size_t)i].second;
     std::vector<int64_t> parent((size_t)(2 * n - 1)), sz((size_t)(2 * n - 1), 0);
     for (int64_t i = 0; i < 2 * n - 1; i++) { parent[i] = i; if (i < n) sz[i] = 1; }
     auto find = [&](int64_t x) {

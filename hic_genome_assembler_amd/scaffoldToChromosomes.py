@@ -82,9 +82,11 @@ def buildAdjacencyMatrix(matrixFile, binList, binID_dict=False, device=0, ctx=No
     return DeviceMatrix(ctx)
 
 
-def removeRows(matrix: DeviceMatrix, binList, zeroRows=True, biasVals=False):
+def removeRows(matrix: DeviceMatrix, binList, zeroRows=True, biasVals=False, store_row_sums=True):
     """S2C:100-136: drop rows (and columns) whose NumPy row sum is 0, then store each bin's
-    left-to-right row sum.  ``biasVals`` filtering is kept for signature compatibility."""
+    left-to-right row sum.  ``biasVals`` filtering is kept for signature compatibility.
+    ``store_row_sums=False``: the caller writes ``Bin.rowSum`` itself, later (``matrix.seq_sum`` holds the values;
+    runResident does it beside the chain)."""
     np_sum, seq_sum = matrix.ctx.row_sums()
     first, world = getattr(matrix.ctx, "shard", (0, 1))
     if world > 1:                                          # one map over several GPUs: every rank summed its own rows
@@ -104,9 +106,14 @@ def removeRows(matrix: DeviceMatrix, binList, zeroRows=True, biasVals=False):
         binList = [binList[i] for i in keep]
         np_sum, seq_sum = matrix.ctx.row_sums()
     matrix.np_sum, matrix.seq_sum = np_sum, seq_sum
+    if store_row_sums:
+        _store_row_sums(binList, seq_sum)
+    return matrix, binList
+
+
+def _store_row_sums(binList, seq_sum):
     for b, v in zip(binList, np.asarray(seq_sum, dtype=np.float64).tolist()):
         b.rowSum = v
-    return matrix, binList
 
 
 def convertMatrix(adjacencyMatrix: DeviceMatrix, binList, distance=True, similarity=False):
@@ -119,7 +126,7 @@ def convertMatrix(adjacencyMatrix: DeviceMatrix, binList, distance=True, similar
     return adjacencyMatrix
 
 
-def averageClusterNodes(adjacencyMatrix: DeviceMatrix, nodeLabels, noPlot=True, meanwhile=None):
+def averageClusterNodes(adjacencyMatrix: DeviceMatrix, nodeLabels, noPlot=True, meanwhile=None, want_ivl=True):
     """S2C:187-208: UPGMA + count-sorted leaf order.  Returns a dict with the two keys of SciPy's
     dendrogram object the reference uses ('ivl', 'leaves') plus the linkage matrix 'Z'.
     ``meanwhile``: host work that does not need the tree; it runs on this thread while the chain - one native call of
@@ -150,7 +157,7 @@ def averageClusterNodes(adjacencyMatrix: DeviceMatrix, nodeLabels, noPlot=True, 
         nodeLabels = nodeLabels()
     print("Time to cluster " + str(time.time() - t0))
     leaves = np.asarray(leaves).tolist()
-    return {"ivl": [nodeLabels[i] for i in leaves], "leaves": leaves, "Z": z}
+    return {"ivl": [nodeLabels[i] for i in leaves] if want_ivl else None, "leaves": leaves, "Z": z}
 
 
 def dendrogramLeafOrder_toFile(dendrogramObj, outFile, lines=None):
@@ -636,7 +643,7 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
             # the scans are computed for rows == shard[0] (mod shard[1]) only and all-gathered; UPGMA and the host control
             # flow run on every rank (deterministic: all ranks write the same files)
             adjMat.ctx.set_row_shard(shard[0], shard[1])
-        adjMat, binList = removeRows(adjMat, binList, zeroRows=True, biasVals=False)
+        adjMat, binList = removeRows(adjMat, binList, zeroRows=True, biasVals=False, store_row_sums=False)
         adjMat.kept_bins = list(binList)                  # rows of the device matrix, in .bed order
         adjMat = convertMatrix(adjMat, binList, distance=True, similarity=False)
         mark("row sums")
@@ -644,7 +651,8 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
         # the size table and the scaffold -> bins table of the assessment
         prep = {}
 
-        def meanwhile(bl=binList):
+        def meanwhile(bl=binList, sums=adjMat.seq_sum):
+            _store_row_sums(bl, sums)                     # (Bin.rowSum, S2C:133-135: nothing reads it before the chain ends)
             prep["labels"] = [b.chrom + '_' + str(b.ID) for b in bl]
             prep["sizes"] = readSizeFileToDict(hicProScaffSizeFile)
             prep["scaffolds"] = _scaffold_bins((b.ID, b.chrom) for b in bl)
@@ -654,7 +662,8 @@ def runResident(adjMat: DeviceMatrix, binList, hicProScaffSizeFile, dendrogramOr
             prep["dend_lines"] = [lab + "\t" + str(i) for i, lab in enumerate(prep["labels"])]
             prep["bin_lines"] = {b.ID: _bin_line(b) for b in bl}
             prep["entry_lines"] = {int(b.ID): str(int(b.ID)) + "\t" + str(b.chrom) + "\n" for b in bl}
-        dendrogram = averageClusterNodes(adjMat, lambda: prep["labels"], noPlot=True, meanwhile=meanwhile)
+        # ('ivl', the labels in leaf order, is only wanted by the dendrogram file, whose lines are ready: prep["dend_lines"])
+        dendrogram = averageClusterNodes(adjMat, lambda: prep["labels"], noPlot=True, meanwhile=meanwhile, want_ivl=False)
         mark("UPGMA + leaf order")
         # the reference parses the file back (readDengrogramLeavesFromFile); the leaves are the same integers
         adjMat, binList = reorderMatrix(adjMat, binList, dendrogram['leaves'])
