@@ -417,23 +417,36 @@ def readBinGroupingsFromFile(binGroupingsFile):
     return groups
 
 
-def _assess_group(pairs, scaffDict, out, percentToAssign):
-    """assessClusterList on (bin, scaffold) pairs; ``out`` collects the report lines."""
+def _assess_rows(pairs, scaffDict, percentToAssign):
+    """The decisions of assessClusterList on (bin, scaffold) pairs: (rows of the report - scaffold, bins here, bins in
+    all, percentage -, the bins of the scaffolds assigned, their names, bins of the others)."""
     members = collections.Counter(map(_second, pairs))       # (a dict: scaffolds in order of first appearance)
-    final, assigned, false_pos = [], 0, 0
-    out.append("#Scaffold\tNodesAssigend\tTotalNodes\tAssigned%\n")
+    rows, final, names, false_pos = [], [], [], 0
     for s, have in members.items():
         total = len(scaffDict[s])
         pct = round(((float(have) / float(total)) * 100.), 2)
-        out.append(str(s) + "\t" + str(have) + "\t" + str(total) + "\t" + str(pct) + "%\n")
+        rows.append((s, have, total, pct))
         if pct >= percentToAssign:
             final += scaffDict[s]
-            assigned += 1
+            names.append(s)
         else:
             false_pos += have
-    out.append("Total scaffolds clustered to chromosome " + str(len(members)) + "\n")
+    return rows, final, names, false_pos
+
+
+def _assess_text(rows, assigned, out):
+    out.append("#Scaffold\tNodesAssigend\tTotalNodes\tAssigned%\n")
+    for s, have, total, pct in rows:
+        out.append(str(s) + "\t" + str(have) + "\t" + str(total) + "\t" + str(pct) + "%\n")
+    out.append("Total scaffolds clustered to chromosome " + str(len(rows)) + "\n")
     out.append("Total scaffolds assigned to chromosome " + str(assigned) + "\n")
-    return final, false_pos, assigned
+
+
+def _assess_group(pairs, scaffDict, out, percentToAssign):
+    """assessClusterList on (bin, scaffold) pairs; ``out`` collects the report lines."""
+    rows, final, names, false_pos = _assess_rows(pairs, scaffDict, percentToAssign)
+    _assess_text(rows, len(names), out)
+    return final, false_pos, len(names)
 
 
 _second = operator.itemgetter(1)
@@ -493,32 +506,54 @@ def assessChromosomeClustering(chromList, statsFile, percentToAssign=51., write=
     groups = [_pairs_of_lines(grp) for grp in chromList]
     if scaffolds is None:
         scaffolds = _scaffold_bins(p for grp in groups for p in grp)
-    final, false_pos, assigned, out = [], 0, 0, []
-    for k, grp in enumerate(groups):
-        out.append("### Chromosome" + str(k + 1) + " ###\n")
-        nodes, fp, na = _assess_group(grp, scaffolds, out, percentToAssign)
+    final, false_pos, assigned, per_group = GroupList(), 0, 0, []
+    for grp in groups:
+        rows, nodes, names, fp = _assess_rows(grp, scaffolds, percentToAssign)
+        per_group.append((rows, len(names)))
         if len(nodes) > 0:
             final.append(nodes)
+            final.scaffolds.append(names)
         false_pos += fp
-        assigned += na
-        out.append("####################\n")
+        assigned += len(names)
     total = sum(len(grp) for grp in groups)
-    out.append("Total Nodes " + str(total) + "\n")
-    out.append("Properly clustered nodes " + str(total - false_pos) + "\n")
-    out.append("Falsely clustered nodes " + str(false_pos) + "\n")
-    out.append("Total scaffolds assigned to chromosomes " + str(assigned) + "\n")
-    out.append("Error rate ~" + str(round((float(false_pos) / float(total)) * 100., 2)) + "%\n")
-    if write is None:
+
+    def report():
+        """The text of the file (formatted where it is written: on the writer thread when ``write`` defers it)."""
+        out = []
+        for k, (rows, n_assigned) in enumerate(per_group):
+            out.append("### Chromosome" + str(k + 1) + " ###\n")
+            _assess_text(rows, n_assigned, out)
+            out.append("####################\n")
+        out.append("Total Nodes " + str(total) + "\n")
+        out.append("Properly clustered nodes " + str(total - false_pos) + "\n")
+        out.append("Falsely clustered nodes " + str(false_pos) + "\n")
+        out.append("Total scaffolds assigned to chromosomes " + str(assigned) + "\n")
+        out.append("Error rate ~" + str(round((float(false_pos) / float(total)) * 100., 2)) + "%\n")
         _write_text(statsFile, "".join(out))
+    if write is None:
+        report()
     else:
-        write(_write_text, statsFile, "".join(out))
+        write(report)
     return final
+
+
+class GroupList(list):
+    """assessChromosomeClustering's result: the groups' [bin, scaffold] entries, and beside them (``scaffolds``) the names of
+    the scaffolds of every group - what rankChromosomeGroups would otherwise collect from all the entries again."""
+
+    def __init__(self, *a):
+        super().__init__(*a)
+        self.scaffolds = []
 
 
 def rankChromosomeGroups(chromList, scaffSizeDict):
     """The order in which S2C:1079-1100 writes the groups: by total scaffold bp, largest first (stable).  What
     orderGenome.readChromsFromFile gives back for the file written from it."""
-    sizes = [sum(scaffSizeDict[s] for s in {e[1]: '' for e in grp}) for grp in chromList]
+    names = getattr(chromList, "scaffolds", None)
+    if names is not None and len(names) == len(chromList):
+        sizes = [sum(scaffSizeDict[s] for s in grp_names) for grp_names in names]
+    else:
+        sizes = [sum(scaffSizeDict[s] for s in {e[1]: '' for e in grp}) for grp in chromList]
     ranked = sorted(range(len(chromList)), key=lambda k: sizes[k], reverse=True)
     return [chromList[k] for k in ranked]
 
