@@ -738,7 +738,7 @@ def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds
             else:
                 states = dict(map(start, todo))
             marks.append(time.perf_counter())
-            jobs, job_of, inserted = [], [], {}
+            jobs, job_of = [], []
             for i in todo:
                 job = _insertion_job(states[i]["ordered"], states[i]["rest"], lanes[i])
                 if job is not None:
@@ -746,17 +746,17 @@ def orderGenome(matrix: GenomeMatrix, chromList, binList, resolution, nScaffolds
                     job_of.append(i)
             if on_native_phase is not None:
                 on_native_phase()                     # a long native call follows: background Python work may take the GIL
-            for i, (ids, rev, best) in zip(job_of, matrix.ctx.p2_insert_all_multi(jobs)):
-                st = states[i]
-                inserted[i] = (_insertion_result(ids, rev, st["ordered"], st["rest"], lanes[i]), best)
+            raw = dict(zip(job_of, matrix.ctx.p2_insert_all_multi(jobs)))     # (turned into scaffold lists by the scan threads)
             marks.append(time.perf_counter())
 
             def finish(i):
                 tf = time.perf_counter()
                 st = states[i]
-                if i not in inserted:                                           # e.g. nothing left to add (OG:475-493)
-                    inserted[i] = orderRemainderScaffolds(st["ordered"], st["rest"], st["orderDict"], lanes[i], binList)
-                ordered, best = inserted[i]
+                if i in raw:
+                    ids, rev, best = raw[i]
+                    ordered = _insertion_result(ids, rev, st["ordered"], st["rest"], lanes[i])
+                else:                                                           # e.g. nothing left to add (OG:475-493)
+                    ordered, best = orderRemainderScaffolds(st["ordered"], st["rest"], st["orderDict"], lanes[i], binList)
                 res = _finishChromosome(st, ordered, best, lanes[i], binList)
                 # this chromosome's lines of the two output files, formatted here - beside the other chromosomes' native scan
                 # calls - instead of for the whole genome at the very end (2.5 ms at 16k, 5 ms at 32k, nothing to hide behind)
